@@ -1,0 +1,165 @@
+"""ORACLE SUPPORT (test infrastructure only) — mint golden vectors from the upstream reference.
+
+Run in the authoring container (needs /root/reference):   python oracle/make_golden.py
+Writes tests/golden/*.pt.  Inputs are regenerated from fixed seeds by the tests (only outputs and the
+few inputs that are cheap to keep are stored).  The reference modules run on CPU in bf16 through
+oracle/ref_shim.py — its SDPA fallback (attention.py:197-212) and the flex_attention recompute
+branch (causal_model.py:305-348, Inductor C++ backend) are the only reference backends that exist
+off-NVIDIA.
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_shim, wan_oracle as wo  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+TINY = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, freq_dim=256, text_len=512, eps=1e-6,
+            num_frame_per_block=3)
+TEXT_DIM = 128
+GRID = (3, 30, 52)  # 3 latent frames of 60x104 -> 1560 tokens/frame (the only size the reference supports)
+
+
+def tiny_inputs(seed=42):
+    g = torch.Generator().manual_seed(seed)
+    lat = [torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16) for _ in range(4)]
+    ctx = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+    return lat, ctx
+
+
+def fresh_caches(cfg, kv_size, dtype=torch.bfloat16):
+    hd = cfg["dim"] // cfg["num_heads"]
+    return (wo.initialize_kv_cache(cfg["num_layers"], 1, kv_size, cfg["num_heads"], hd, dtype),
+            wo.initialize_crossattn_cache(cfg["num_layers"], 1, cfg["num_heads"], hd, dtype))
+
+
+def cache_sample(kv_cache):
+    return [{"k": c["k"][0, ::197].clone(), "v": c["v"][0, ::197].clone(),
+             "global_end_index": int(c["global_end_index"]), "local_end_index": int(c["local_end_index"])}
+            for c in kv_cache]
+
+
+def golden_ops(ref):
+    g = torch.Generator().manual_seed(1)
+    out = {}
+    q = torch.randn(1, 300, 2, 128, generator=g).to(torch.bfloat16)
+    k = torch.randn(1, 500, 2, 128, generator=g).to(torch.bfloat16)
+    v = torch.randn(1, 500, 2, 128, generator=g).to(torch.bfloat16)
+    out["attn_q"], out["attn_k"], out["attn_v"] = q, k, v
+    out["attn_out"] = ref.attention.attention(q, k, v)
+    # RoPE (causal, start frame 3) and non-causal
+    x = torch.randn(1, 2 * 6 * 8, 2, 128, generator=g).to(torch.bfloat16)
+    freqs = ref.cm.CausalWanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=TEXT_DIM).freqs
+    grid = torch.tensor([[2, 6, 8]])
+    out["rope_x"] = x
+    out["rope_causal_s3"] = ref.cm.causal_rope_apply(x, grid, freqs, start_frame=3)
+    out["rope_s0"] = ref.model.rope_apply(x, grid, freqs)
+    out["freqs_sample"] = torch.view_as_real(freqs[[0, 1, 5, 100, 1023]]).clone()
+    # norms
+    y = torch.randn(4, 7, 256, generator=g).to(torch.bfloat16)
+    wgt = (1 + 0.1 * torch.randn(256, generator=g)).to(torch.bfloat16)
+    rn = ref.model.WanRMSNorm(256, eps=1e-6).to(torch.bfloat16)
+    rn.weight.data.copy_(wgt)
+    out["norm_x"], out["norm_w"] = y, wgt
+    out["rms"] = rn(y)
+    out["ln"] = ref.model.WanLayerNorm(256, eps=1e-6)(y)
+    # scheduler / schedule / x0
+    sch = ref.scheduler.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    out["sched_timesteps"] = sch.timesteps.clone()
+    out["sched_sigmas"] = sch.sigmas.clone()
+    zp = torch.cat((sch.timesteps, torch.tensor([0], dtype=torch.float32)))
+    out["schedule_4"] = ref.get_denoising_schedule(zp, 1.0, 4)
+    out["schedule_5"] = ref.get_denoising_schedule(zp, 1.0, 5)
+    out["schedule_4_s07"] = ref.get_denoising_schedule(zp, 0.7, 4)
+    x0 = torch.randn(3, 16, 6, 8, generator=g).to(torch.bfloat16)
+    nz = torch.randn(3, 16, 6, 8, generator=g).to(torch.bfloat16)
+    tt = out["schedule_4"][1] * torch.ones([3], dtype=torch.long)
+    out["an_x0"], out["an_noise"], out["an_t"] = x0, nz, tt
+    out["an_out"] = sch.add_noise(x0, nz, tt)
+    W = ref.wan_wrapper.WanDiffusionWrapper
+    wr = W.__new__(W)
+    torch.nn.Module.__init__(wr)
+    wr.scheduler = sch
+    out["x0_out"] = wr._convert_flow_pred_to_x0(x0, nz, tt.to(torch.float32))
+    out["sinus"] = ref.cm.sinusoidal_embedding_1d(256, out["schedule_4"])
+    torch.save(out, os.path.join(OUT, "ops.pt"))
+    print("ops.pt", sum(v.numel() * v.element_size() for v in out.values() if torch.is_tensor(v)) / 1e6, "MB")
+
+
+def golden_dit(ref):
+    """Server-path sequence on the tiny model, c = 3."""
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    lat, ctx = tiny_inputs()
+    model = build = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    kv, ca = fresh_caches(cfg, 9360)
+    cond = {"prompt_embeds": [ctx]}
+    sched = wr.scheduler
+    zp = torch.cat((sched.timesteps, torch.tensor([0], dtype=torch.float32)))
+    steps = ref.get_denoising_schedule(zp, 1.0, 4)
+    out = {"weights_checksum": float(sum(v.double().abs().sum() for v in w.values())), "steps": steps}
+
+    def ts(v):
+        return torch.ones([1, 3], dtype=torch.int64) * v
+
+    with torch.inference_mode():
+        # block 0, step 0 and step 1 at current_start = 0 (second call overwrites the same rows)
+        flow, x0 = wr(lat[0], cond, ts(steps[0]), kv, ca, current_start=0)
+        out["b0s0_flow"], out["b0s0_x0"] = flow.clone(), x0.clone()
+        out["b0s0_cache"] = cache_sample(kv)
+        flow, x0 = wr(lat[1], cond, ts(steps[1]), kv, ca, current_start=0)
+        out["b0s1_flow"] = flow.clone()
+        out["b0s1_cache"] = cache_sample(kv)
+        # recompute (flex branch): zero caches, block mask, t = 0, clean frames = lat[2]
+        for c in kv:
+            c["k"].zero_()
+            c["v"].zero_()
+            c["global_end_index"] = 0
+            c["local_end_index"] = 0
+        model.block_mask = model._prepare_blockwise_causal_attn_mask(
+            device="cpu", num_frames=3, frame_seqlen=1560, num_frame_per_block=3, local_attn_size=-1)
+        flow, _ = wr(lat[2], cond, torch.zeros([1, 3], dtype=torch.int64), kv, ca, current_start=3 * 1560)
+        model.block_mask = None
+        out["rc_flow"] = flow.clone()
+        out["rc_cache"] = cache_sample(kv)
+        # block 1 denoise at current_start = 4680 -> attends 9360 keys
+        flow, x0 = wr(lat[3], cond, ts(steps[0]), kv, ca, current_start=4680)
+        out["b1s0_flow"], out["b1s0_x0"] = flow.clone(), x0.clone()
+        out["b1s0_cache"] = cache_sample(kv)
+    torch.save(out, os.path.join(OUT, "dit_server_path.pt"))
+    print("dit_server_path.pt done")
+
+
+def golden_rolling(ref):
+    """Rolling cache with attention sink (causal_model.py:359-385): local_attn_size=6, sink_size=1."""
+    cfg = dict(TINY, local_attn_size=6, sink_size=1, num_layers=1)
+    w = wo.make_weights(cfg, seed=3, text_dim=TEXT_DIM)
+    lat, ctx = tiny_inputs(seed=7)
+    model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    kv, ca = fresh_caches(cfg, 6 * 1560)
+    cond = {"prompt_embeds": [ctx]}
+    out = {"indices": [], "flow_sample": []}
+    with torch.inference_mode():
+        for b in range(4):
+            t = torch.ones([1, 3], dtype=torch.int64) * 500
+            flow, _ = wr(lat[b], cond, t, kv, ca, current_start=b * 4680)
+            out["indices"].append((int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"])))
+            out["flow_sample"].append(flow[0, :, :, ::3, ::4].clone())
+        out["cache"] = cache_sample(kv)
+    torch.save(out, os.path.join(OUT, "dit_rolling.pt"))
+    print("dit_rolling.pt", out["indices"])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    ref = ref_shim.load()
+    golden_ops(ref)
+    golden_dit(ref)
+    golden_rolling(ref)

@@ -1,0 +1,472 @@
+"""CPU ORACLE (test infrastructure only) — restatement of the reference's causal Wan DiT hot path.
+
+This file is a checker, not a product path: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  It restates, op for op, the reference's eager PyTorch algorithm for
+the per-denoising-step DiT forward with KV cache, so that it can run (a) in bf16 exactly like the
+reference's CPU/eager path and (b) in fp32/fp64 as a "gold" graph to bound rounding error.
+
+Parity pinning: the upstream repo has NO tests or golden vectors for this path, so
+the oracle is pinned against the reference's own modules imported in the authoring container
+(oracle/ref_shim.py + oracle/make_golden.py -> tests/golden/*.pt; tests/test_oracle_vs_golden.py).
+
+Every function cites the reference file:line it follows (paths under the upstream repo root).
+Weights are plain dicts keyed by the reference's state_dict names.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+FRAME_SEQLEN = 1560  # hard-coded in the reference: causal_model.py:351, causal_inference.py:35
+
+
+# ------------------------------------------------------------------------------------------------
+# embeddings / tables
+# ------------------------------------------------------------------------------------------------
+def sinusoidal_embedding_1d(dim, position):
+    """wan/modules/model.py:15-24 (float64; device-agnostic)."""
+    assert dim % 2 == 0
+    half = dim // 2
+    position = position.type(torch.float64)
+    sinusoid = torch.outer(position, torch.pow(10000, -torch.arange(half, dtype=torch.float64).div(half)))
+    return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
+
+
+def rope_params(max_seq_len, dim, theta=10000):
+    """wan/modules/model.py:28-35 -> complex128 [max_seq_len, dim/2]."""
+    assert dim % 2 == 0
+    freqs = torch.outer(torch.arange(max_seq_len),
+                        1.0 / torch.pow(theta, torch.arange(0, dim, 2).to(torch.float64).div(dim)))
+    return torch.polar(torch.ones_like(freqs), freqs)
+
+
+def rope_table(head_dim):
+    """wan/modules/causal_model.py:637-645: [1024, head_dim/2] complex128 = cat(frame | h | w parts)."""
+    d = head_dim
+    return torch.cat([rope_params(1024, d - 4 * (d // 6)), rope_params(1024, 2 * (d // 6)),
+                      rope_params(1024, 2 * (d // 6))], dim=1)
+
+
+def rope_apply(x, grid, freqs, start_frame=0):
+    """causal_rope_apply (causal_model.py:143-171); start_frame=0 gives rope_apply (model.py:39-66).
+    x: [B, S, H, hd]; grid = (F, h, w); computed in float64, cast back with .type_as(x)."""
+    n, c = x.size(2), x.size(3) // 2
+    parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+    f, h, w = grid
+    seq_len = f * h * w
+    out = []
+    for i in range(x.size(0)):
+        x_i = torch.view_as_complex(x[i, :seq_len].to(torch.float64).reshape(seq_len, n, -1, 2))
+        freqs_i = torch.cat([
+            parts[0][start_frame:start_frame + f].view(f, 1, 1, -1).expand(f, h, w, -1),
+            parts[1][:h].view(1, h, 1, -1).expand(f, h, w, -1),
+            parts[2][:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(seq_len, 1, -1)
+        x_i = torch.view_as_real(x_i * freqs_i).flatten(2)
+        x_i = torch.cat([x_i, x[i, seq_len:]])
+        out.append(x_i)
+    return torch.stack(out).type_as(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+def rms_norm(x, weight, eps=1e-6):
+    """WanRMSNorm.forward, model.py:77-85: fp32 math, .type_as(x), then * weight; over the FULL dim."""
+    xf = x.float()
+    return (xf * torch.rsqrt(xf.pow(2).mean(dim=-1, keepdim=True) + eps)).type_as(x) * weight
+
+
+def layer_norm(x, eps=1e-6, weight=None, bias=None):
+    """WanLayerNorm.forward, model.py:88-98."""
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps).type_as(x)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention backends
+# ------------------------------------------------------------------------------------------------
+def attention_sdpa(q, k, v, dtype=torch.bfloat16):
+    """SDPA fallback of attention(), wan/modules/attention.py:197-212 (BLHD in, BLHD contiguous out,
+    result stays in `dtype`).  Pass dtype=None to keep the input dtype (gold fp32 runs)."""
+    if dtype is not None:
+        q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    out = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2))
+    return out.transpose(1, 2).contiguous()
+
+
+def attention_math(q, k, v, kv_limit=None):
+    """Definition-level attention in fp32: softmax(q k^T / sqrt(d)) v with optional per-query key-prefix
+    limits (kv_limit[i] = number of leading keys query i may see).  BLHD."""
+    qf, kf, vf = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) / math.sqrt(q.shape[-1])
+    if kv_limit is not None:
+        kv_idx = torch.arange(k.shape[1]).view(1, 1, 1, -1)
+        s = s.masked_fill(kv_idx >= kv_limit.view(1, 1, -1, 1), float("-inf"))
+    return (torch.softmax(s, dim=-1) @ vf).transpose(1, 2).contiguous()
+
+
+def block_causal_limits(total_len, block_len):
+    """`ends` array of get_block_mask, causal_model.py:119-136 (without the 128-padding rows):
+    query i attends keys < ends[i] = (i // block_len + 1) * block_len."""
+    idx = torch.arange(total_len)
+    return torch.clamp((idx // block_len + 1) * block_len, max=total_len)
+
+
+def attention_block_causal(q, k, v, block_len):
+    """flex_attention with the block mask of causal_model.py:108-141 / :339-348.  The reference pads
+    q/k/v with zero rows to a multiple of 128; pad keys are masked for real queries (kv < ends[q])
+    and pad query rows are dropped (:348), so the un-padded masked attention is equivalent."""
+    lim = block_causal_limits(q.shape[1], block_len)
+    return attention_math(q, k, v, kv_limit=lim).to(q.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# KV cache manager (pipeline/causal_inference.py:279-339)
+# ------------------------------------------------------------------------------------------------
+def initialize_kv_cache(num_layers, batch_size, kv_cache_size, num_heads, head_dim, dtype):
+    """causal_inference.py:279-314 (fresh allocation branch)."""
+    return [{"k": torch.zeros(batch_size, kv_cache_size, num_heads, head_dim, dtype=dtype),
+             "v": torch.zeros(batch_size, kv_cache_size, num_heads, head_dim, dtype=dtype),
+             "global_end_index": 0, "local_end_index": 0} for _ in range(num_layers)]
+
+
+def reset_kv_cache(kv_cache):
+    """causal_inference.py:296-302 (zero re-initialisation branch)."""
+    for c in kv_cache:
+        c["k"].zero_()
+        c["v"].zero_()
+        c["global_end_index"] = 0
+        c["local_end_index"] = 0
+
+
+def initialize_crossattn_cache(num_layers, batch_size, num_heads, head_dim, dtype, text_len=512):
+    """causal_inference.py:316-339."""
+    return [{"k": torch.zeros(batch_size, text_len, num_heads, head_dim, dtype=dtype),
+             "v": torch.zeros(batch_size, text_len, num_heads, head_dim, dtype=dtype),
+             "is_init": False} for _ in range(num_layers)]
+
+
+# ------------------------------------------------------------------------------------------------
+# DiT block
+# ------------------------------------------------------------------------------------------------
+def _lin(x, w, prefix):
+    return F.linear(x, w[prefix + ".weight"], w[prefix + ".bias"])
+
+
+def self_attention(w, pre, x, grid, freqs, num_heads, kv_cache, current_start, recompute,
+                   num_frame_per_block=3, local_attn_size=-1, sink_size=0, eps=1e-6, attn_fn=None):
+    """CausalWanSelfAttention.forward, causal_model.py:218-397.
+    recompute=True is the `block_mask is not None` branch (:305-348); otherwise the cached branch
+    (:349-392) including the rolling eviction (:363-379).  Mutates kv_cache exactly like the reference."""
+    b, s, n = x.shape[0], x.shape[1], num_heads
+    d = x.shape[2] // n
+    attn_fn = attn_fn or attention_sdpa
+    q = rms_norm(_lin(x, w, pre + ".q"), w[pre + ".norm_q.weight"], eps).view(b, s, n, d)
+    k = rms_norm(_lin(x, w, pre + ".k"), w[pre + ".norm_k.weight"], eps).view(b, s, n, d)
+    v = _lin(x, w, pre + ".v").view(b, s, n, d)
+
+    if recompute:
+        rq = rope_apply(q, grid, freqs).type_as(v)
+        rk = rope_apply(k, grid, freqs).type_as(v)
+        local_end = rk.shape[1]
+        kv_cache["k"][:, :local_end] = rk
+        kv_cache["v"][:, :local_end] = v
+        kv_cache["global_end_index"] = local_end
+        kv_cache["local_end_index"] = local_end
+        out = attention_block_causal(rq, rk, v, FRAME_SEQLEN * num_frame_per_block)
+    else:
+        frame_seqlen = FRAME_SEQLEN
+        start_frame = current_start // frame_seqlen
+        rq = rope_apply(q, grid, freqs, start_frame).type_as(v)
+        rk = rope_apply(k, grid, freqs, start_frame).type_as(v)
+        current_end = current_start + rq.shape[1]
+        sink_tokens = sink_size * frame_seqlen
+        kv_cache_size = kv_cache["k"].shape[1]
+        num_new = rq.shape[1]
+        max_attention_size = 32760 if local_attn_size == -1 else local_attn_size * 1560
+        if local_attn_size != -1 and current_end > kv_cache["global_end_index"] and \
+                num_new + kv_cache["local_end_index"] > kv_cache_size:
+            evicted = num_new + kv_cache["local_end_index"] - kv_cache_size
+            rolled = kv_cache["local_end_index"] - evicted - sink_tokens
+            kv_cache["k"][:, sink_tokens:sink_tokens + rolled] = \
+                kv_cache["k"][:, sink_tokens + evicted:sink_tokens + evicted + rolled].clone()
+            kv_cache["v"][:, sink_tokens:sink_tokens + rolled] = \
+                kv_cache["v"][:, sink_tokens + evicted:sink_tokens + evicted + rolled].clone()
+            local_end = kv_cache["local_end_index"] + current_end - kv_cache["global_end_index"] - evicted
+        else:
+            local_end = kv_cache["local_end_index"] + current_end - kv_cache["global_end_index"]
+        local_start = local_end - num_new
+        kv_cache["k"][:, local_start:local_end] = rk
+        kv_cache["v"][:, local_start:local_end] = v
+        lo = max(0, local_end - max_attention_size)
+        out = attn_fn(rq, kv_cache["k"][:, lo:local_end], kv_cache["v"][:, lo:local_end])
+        kv_cache["global_end_index"] = current_end
+        kv_cache["local_end_index"] = local_end
+    return _lin(out.flatten(2), w, pre + ".o")
+
+
+def cross_attention(w, pre, x, context, num_heads, crossattn_cache, eps=1e-6, attn_fn=None):
+    """WanT2VCrossAttention.forward, model.py:171-228 (SDPA branch :216-223)."""
+    b, n = x.size(0), num_heads
+    d = x.shape[2] // n
+    attn_fn = attn_fn or attention_sdpa
+    q = rms_norm(_lin(x, w, pre + ".q"), w[pre + ".norm_q.weight"], eps).view(b, -1, n, d)
+    if crossattn_cache is not None and crossattn_cache["is_init"]:
+        k, v = crossattn_cache["k"], crossattn_cache["v"]
+    else:
+        k = rms_norm(_lin(context, w, pre + ".k"), w[pre + ".norm_k.weight"], eps).view(b, -1, n, d)
+        v = _lin(context, w, pre + ".v").view(b, -1, n, d)
+        if crossattn_cache is not None:
+            crossattn_cache["is_init"] = True
+            crossattn_cache["k"] = k
+            crossattn_cache["v"] = v
+    out = attn_fn(q, k, v)
+    return _lin(out.flatten(2), w, pre + ".o")
+
+
+def attention_block(w, pre, x, e, grid, freqs, context, num_heads, kv_cache, crossattn_cache,
+                    current_start, recompute, eps=1e-6, attn_fn=None, **sa_kwargs):
+    """CausalWanAttentionBlock.forward, causal_model.py:440-492.  e: [B, F, 6, C]."""
+    num_frames, frame_seqlen = e.shape[1], x.shape[1] // e.shape[1]
+    e = (w[pre + ".modulation"].unsqueeze(1) + e).chunk(6, dim=2)
+
+    def per_frame(t):
+        return t.unflatten(dim=1, sizes=(num_frames, frame_seqlen))
+
+    y = self_attention(w, pre + ".self_attn", (per_frame(layer_norm(x, eps)) * (1 + e[1]) + e[0]).flatten(1, 2),
+                       grid, freqs, num_heads, kv_cache, current_start, recompute, eps=eps, attn_fn=attn_fn,
+                       **sa_kwargs)
+    x = x + (per_frame(y) * e[2]).flatten(1, 2)
+    x = x + cross_attention(w, pre + ".cross_attn",
+                            layer_norm(x, eps, w[pre + ".norm3.weight"], w[pre + ".norm3.bias"]),
+                            context, num_heads, crossattn_cache, eps, attn_fn=attn_fn)
+    h = (per_frame(layer_norm(x, eps)) * (1 + e[4]) + e[3]).flatten(1, 2)
+    y = _lin(F.gelu(_lin(h, w, pre + ".ffn.0"), approximate="tanh"), w, pre + ".ffn.2")
+    x = x + (per_frame(y) * e[5]).flatten(1, 2)
+    return x
+
+
+def head(w, x, e, eps=1e-6):
+    """CausalHead.forward, causal_model.py:512-523.  e: [B, F, 1, C]."""
+    num_frames, frame_seqlen = e.shape[1], x.shape[1] // e.shape[1]
+    e = (w["head.modulation"].unsqueeze(1) + e).chunk(2, dim=2)
+    h = layer_norm(x, eps).unflatten(dim=1, sizes=(num_frames, frame_seqlen)) * (1 + e[1]) + e[0]
+    return F.linear(h, w["head.head.weight"], w["head.head.bias"])
+
+
+def unpatchify(x, grid, out_dim=16, patch_size=(1, 2, 2)):
+    """causal_model.py:1126-1149 for one sample: x [L, out_dim*4] -> [out_dim, F, 2h, 2w]."""
+    u = x[:math.prod(grid)].view(*grid, *patch_size, out_dim)
+    u = torch.einsum("fhwpqrc->cfphqwr", u)
+    return u.reshape(out_dim, *[i * j for i, j in zip(grid, patch_size)])
+
+
+# ------------------------------------------------------------------------------------------------
+# model / wrapper
+# ------------------------------------------------------------------------------------------------
+def model_forward(w, cfg, x, t, context, kv_cache, crossattn_cache, current_start=0, recompute=False,
+                  attn_fn=None):
+    """CausalWanModel._forward_inference, causal_model.py:825-954 (B == 1).
+    x: [B, 16, F, H, W]; t: [B, F]; context: list of [L_txt, text_dim]; returns [B, 16, F, H, W].
+    cfg keys: dim, ffn_dim, num_heads, num_layers, freq_dim, text_len, eps (+ local_attn_size, sink_size).
+    `recompute` mirrors `self.block_mask is not None` (release_server.py:611-632)."""
+    dim, n_heads, eps = cfg["dim"], cfg["num_heads"], cfg.get("eps", 1e-6)
+    freqs = rope_table(dim // n_heads)
+    outs = []
+    xs = [F.conv3d(u.unsqueeze(0), w["patch_embedding.weight"], w["patch_embedding.bias"], stride=(1, 2, 2))
+          for u in x]
+    grid = tuple(xs[0].shape[2:])
+    xs = torch.cat([u.flatten(2).transpose(1, 2) for u in xs])
+    e = sinusoidal_embedding_1d(cfg.get("freq_dim", 256), t.flatten()).type_as(xs)
+    e = F.linear(F.silu(F.linear(e, w["time_embedding.0.weight"], w["time_embedding.0.bias"])),
+                 w["time_embedding.2.weight"], w["time_embedding.2.bias"])
+    e0 = F.linear(F.silu(e), w["time_projection.1.weight"], w["time_projection.1.bias"]) \
+        .unflatten(1, (6, dim)).unflatten(dim=0, sizes=t.shape)
+    text_len = cfg.get("text_len", 512)
+    ctx = torch.stack([torch.cat([u, u.new_zeros(text_len - u.size(0), u.size(1))]) for u in context])
+    ctx = F.linear(F.gelu(F.linear(ctx, w["text_embedding.0.weight"], w["text_embedding.0.bias"]),
+                          approximate="tanh"), w["text_embedding.2.weight"], w["text_embedding.2.bias"])
+    h = xs
+    for i in range(cfg["num_layers"]):
+        h = attention_block(w, f"blocks.{i}", h, e0, grid, freqs, ctx, n_heads, kv_cache[i],
+                            crossattn_cache[i], current_start, recompute, eps, attn_fn=attn_fn,
+                            local_attn_size=cfg.get("local_attn_size", -1), sink_size=cfg.get("sink_size", 0),
+                            num_frame_per_block=cfg.get("num_frame_per_block", 3))
+    h = head(w, h, e.unflatten(dim=0, sizes=t.shape).unsqueeze(2), eps)
+    for u in h:
+        outs.append(unpatchify(u, grid))
+    return torch.stack(outs)
+
+
+class FlowMatchScheduler:
+    """utils/scheduler.py:106-176 (set_timesteps :118-141 without the training weights; add_noise :159-176)."""
+
+    def __init__(self, shift=5.0, sigma_min=0.0, extra_one_step=True, num_train_timesteps=1000, sigma_max=1.0):
+        self.shift, self.sigma_min, self.sigma_max = shift, sigma_min, sigma_max
+        self.extra_one_step, self.num_train_timesteps = extra_one_step, num_train_timesteps
+        self.set_timesteps(1000)
+
+    def set_timesteps(self, num_inference_steps=1000, denoising_strength=1.0):
+        sigma_start = self.sigma_min + (self.sigma_max - self.sigma_min) * denoising_strength
+        if self.extra_one_step:
+            self.sigmas = torch.linspace(sigma_start, self.sigma_min, num_inference_steps + 1)[:-1]
+        else:
+            self.sigmas = torch.linspace(sigma_start, self.sigma_min, num_inference_steps)
+        self.sigmas = self.shift * self.sigmas / (1 + (self.shift - 1) * self.sigmas)
+        self.timesteps = self.sigmas * self.num_train_timesteps
+
+    def add_noise(self, original_samples, noise, timestep):
+        if timestep.ndim == 2:
+            timestep = timestep.flatten(0, 1)
+        timestep_id = torch.argmin((self.timesteps.unsqueeze(0) - timestep.unsqueeze(1)).abs(), dim=1)
+        sigma = self.sigmas[timestep_id].reshape(-1, 1, 1, 1)
+        return ((1 - sigma) * original_samples + sigma * noise).type_as(noise)
+
+
+def convert_flow_pred_to_x0(scheduler, flow_pred, xt, timestep):
+    """WanDiffusionWrapper._convert_flow_pred_to_x0, utils/wan_wrapper.py:181-205 (float64)."""
+    original_dtype = flow_pred.dtype
+    flow_pred, xt, sigmas, timesteps = (a.double() for a in (flow_pred, xt, scheduler.sigmas, scheduler.timesteps))
+    timestep_id = torch.argmin((timesteps.unsqueeze(0) - timestep.unsqueeze(1)).abs(), dim=1)
+    sigma_t = sigmas[timestep_id].reshape(-1, 1, 1, 1)
+    return (xt - sigma_t * flow_pred).to(original_dtype)
+
+
+def wrapper_forward(w, cfg, scheduler, noisy, prompt_embeds, timestep, kv_cache, crossattn_cache,
+                    current_start, recompute=False, attn_fn=None):
+    """WanDiffusionWrapper.forward (kv_cache branch), utils/wan_wrapper.py:230-301.
+    noisy: [B, F, 16, H, W]; timestep: [B, F]; returns (flow_pred, pred_x0) both [B, F, 16, H, W]."""
+    flow = model_forward(w, cfg, noisy.permute(0, 2, 1, 3, 4), timestep, prompt_embeds, kv_cache,
+                         crossattn_cache, current_start, recompute, attn_fn).permute(0, 2, 1, 3, 4)
+    x0 = convert_flow_pred_to_x0(scheduler, flow.flatten(0, 1), noisy.flatten(0, 1),
+                                 timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])
+    return flow, x0
+
+
+def get_denoising_schedule(timesteps, denoising_strength, steps=4):
+    """v2v.py:133-136.  `timesteps` = scheduler.timesteps padded with a trailing 0 (release_server.py:559-560)."""
+    lst = torch.linspace(denoising_strength * 1000, 0, steps, dtype=torch.float32).to(torch.long)
+    return timesteps[1000 - lst]
+
+
+# ------------------------------------------------------------------------------------------------
+# block loop (GenerationSession), DiT part only
+# ------------------------------------------------------------------------------------------------
+class SessionOracle:
+    """DiT side of GenerationSession: recompute_kv_cache (release_server.py:588-633) and the denoising
+    loop of generate_block_internal (:636-708) for T2V with keep_first_frame semantics selectable.
+    The VAE decode / first-frame re-encode legs are separate (oracle/vae_oracle.py)."""
+
+    def __init__(self, w, cfg, prompt_embeds, noise, kv_cache_num_frames=3, num_steps=4, shift=5.0,
+                 seed=0, attn_fn=None, first_frame_fn=None):
+        self.w, self.cfg, self.attn_fn = w, cfg, attn_fn
+        self.prompt_embeds = prompt_embeds          # list of [L_txt, text_dim]
+        self.noise = noise                          # [1, num_blocks*3, 16, h, w]
+        self.all_latents = torch.zeros_like(noise)
+        self.c = kv_cache_num_frames
+        self.nfpb = 3
+        self.block_idx = 0
+        self.current_start_frame = 0
+        self.scheduler = FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
+        zp = torch.cat((self.scheduler.timesteps, torch.tensor([0], dtype=torch.float32)))
+        self.denoising_step_list = get_denoising_schedule(zp, 1.0, steps=num_steps)
+        n_heads, hd = cfg["num_heads"], cfg["dim"] // cfg["num_heads"]
+        kv_size = (self.c + self.nfpb) * FRAME_SEQLEN   # init_models, release_server.py:543-549
+        self.kv_cache = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype)
+        self.crossattn_cache = initialize_crossattn_cache(cfg["num_layers"], 1, n_heads, hd, noise.dtype,
+                                                          cfg.get("text_len", 512))
+        self.rnd = torch.Generator().manual_seed(seed)
+        self.first_frame_fn = first_frame_fn        # callable(block_idx) -> latent [1,1,16,h,w] (VAE re-encode)
+
+    def clean_context_frames(self):
+        """get_clean_context_frames, release_server.py:563-576."""
+        ctx = self.all_latents[:, :self.current_start_frame]
+        if self.first_frame_fn is None or (self.block_idx - 1) * self.nfpb < self.c:
+            if self.c == 1:
+                return ctx[:, :1]
+            return torch.cat((ctx[:, :1], ctx[:, 1:][:, -self.c + 1:]), dim=1)
+        tail = ctx[:, 1:][:, -self.c + 1:]
+        return torch.cat((self.first_frame_fn(self.block_idx).to(tail), tail), dim=1)
+
+    def recompute_kv_cache(self):
+        """release_server.py:588-633."""
+        if self.block_idx == 0:
+            reset_kv_cache(self.kv_cache)
+            return self.current_start_frame
+        start = min(self.current_start_frame, self.c)
+        ctx = self.clean_context_frames()
+        reset_kv_cache(self.kv_cache)
+        t0 = torch.zeros([1, ctx.shape[1]], dtype=torch.int64)
+        wrapper_forward(self.w, self.cfg, self.scheduler, ctx, self.prompt_embeds, t0, self.kv_cache,
+                        self.crossattn_cache, start * FRAME_SEQLEN, recompute=True, attn_fn=self.attn_fn)
+        return start
+
+    def generate_block(self):
+        """generate_block_internal, release_server.py:636-708 (T2V branch), returns denoised latents."""
+        start = self.recompute_kv_cache()
+        noisy = self.noise[:, self.current_start_frame:self.current_start_frame + self.nfpb]
+        steps = self.denoising_step_list
+        for index, current_timestep in enumerate(steps):
+            timestep = torch.ones([1, self.nfpb], dtype=torch.int64) * current_timestep  # -> float32 (trap 4)
+            _, denoised = wrapper_forward(self.w, self.cfg, self.scheduler, noisy, self.prompt_embeds, timestep,
+                                          self.kv_cache, self.crossattn_cache, start * FRAME_SEQLEN,
+                                          attn_fn=self.attn_fn)
+            if index < len(steps) - 1:
+                nxt = steps[index + 1]
+                eps_noise = torch.randn(*denoised.flatten(0, 1).shape, generator=self.rnd, dtype=torch.bfloat16) \
+                    .to(denoised.dtype)
+                noisy = self.scheduler.add_noise(denoised.flatten(0, 1), eps_noise,
+                                                 nxt * torch.ones([self.nfpb], dtype=torch.long)) \
+                    .unflatten(0, denoised.shape[:2])
+        self.all_latents[:, self.current_start_frame:self.current_start_frame + self.nfpb] = denoised
+        self.current_start_frame += self.nfpb
+        self.block_idx += 1
+        return denoised
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic weights (SURVEY.md §8d "Synthetic inputs")
+# ------------------------------------------------------------------------------------------------
+def make_weights(cfg, seed=0, dtype=torch.bfloat16, text_dim=4096, in_dim=16, out_dim=16):
+    """Random weights with the reference's state_dict names and init scheme (init_weights,
+    causal_model.py:1151-1173: xavier-uniform Linear weights, zero biases, N(0,.02) text/time MLPs),
+    except head.head.weight ~ N(0,.02) (zero-init in the reference would make every output 0) and small
+    random biases / norm weights near 1 so that every term of the graph is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    dim, ffn, L = cfg["dim"], cfg["ffn_dim"], cfg["num_layers"]
+    freq_dim = cfg.get("freq_dim", 256)
+    w = {}
+
+    def xavier(out_f, in_f):
+        a = math.sqrt(6.0 / (in_f + out_f))
+        return (torch.rand(out_f, in_f, generator=g) * 2 - 1) * a
+
+    def normal(*shape, std=0.02):
+        return torch.randn(*shape, generator=g) * std
+
+    def lin(name, out_f, in_f, init="xavier"):
+        w[name + ".weight"] = xavier(out_f, in_f) if init == "xavier" else normal(out_f, in_f)
+        w[name + ".bias"] = normal(out_f, std=0.02)
+
+    w["patch_embedding.weight"] = xavier(dim, in_dim * 4).view(dim, in_dim, 1, 2, 2)
+    w["patch_embedding.bias"] = normal(dim)
+    lin("text_embedding.0", dim, text_dim, "normal")
+    lin("text_embedding.2", dim, dim, "normal")
+    lin("time_embedding.0", dim, freq_dim, "normal")
+    lin("time_embedding.2", dim, dim, "normal")
+    lin("time_projection.1", dim * 6, dim)
+    for i in range(L):
+        p = f"blocks.{i}"
+        for a in ("self_attn", "cross_attn"):
+            for m in ("q", "k", "v", "o"):
+                lin(f"{p}.{a}.{m}", dim, dim)
+            w[f"{p}.{a}.norm_q.weight"] = 1 + normal(dim, std=0.1)
+            w[f"{p}.{a}.norm_k.weight"] = 1 + normal(dim, std=0.1)
+        w[f"{p}.norm3.weight"] = 1 + normal(dim, std=0.1)
+        w[f"{p}.norm3.bias"] = normal(dim, std=0.05)
+        lin(f"{p}.ffn.0", ffn, dim)
+        lin(f"{p}.ffn.2", dim, ffn)
+        w[f"{p}.modulation"] = torch.randn(1, 6, dim, generator=g) / dim ** 0.5
+    w["head.head.weight"] = normal(out_dim * 4, dim)
+    w["head.head.bias"] = normal(out_dim * 4)
+    w["head.modulation"] = torch.randn(1, 2, dim, generator=g) / dim ** 0.5
+    return {k: v.to(dtype) for k, v in w.items()}

@@ -1,0 +1,99 @@
+"""ctypes binding of librtv_hip.so (the C-ABI HIP kernel library, see include/rtv_hip.h).
+
+The product path has no CPU / eager fallback: if the library is missing or a kernel reports an
+error, a RuntimeError is raised (the reference's attention()/pipeline API reports errors as Python
+exceptions, wan/modules/attention.py:72-73,129).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtv_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (restype is always int except where noted); mirrors include/rtv_hip.h
+SIGNATURES = {
+    "rtv_version": [],
+    "rtv_prof_enable": [c_int],
+    "rtv_prof_read": [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
+                      ctypes.POINTER(ctypes.c_double)],
+    "rtv_prof_reset": [],
+    "rtv_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
+                     c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                     c_f32, c_int, c_int, c_int, c_vp],
+    "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
+                 c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
+    "rtv_layernorm_modulate": [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
+    "rtv_rmsnorm": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp],
+    "rtv_qk_norm_rope_cache": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32,
+                               c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_modulation_table": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_sinusoidal_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
+    "rtv_patchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_unpatchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+}
+# later sections (DiT forward, VAE) register their signatures here as well
+EXTRA_SIGNATURES = {}
+
+
+def build(verbose=False):
+    """Compile librtv_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(os.cpu_count() or 4)]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise RuntimeError("building librtv_hip.so failed")
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Every extern "C" function declared in include/rtv_hip.h (parsed from the header)."""
+    import re
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "rtv_hip.h")
+    text = open(hdr).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtv_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the library (no compute happens here; safe on a CPU-only box)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C realtime_video_amd/csrc`). There is no CPU fallback for the HIP path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.rtv_last_error.restype = ctypes.c_char_p
+    lib.rtv_last_error.argtypes = []
+    sigs = dict(SIGNATURES)
+    sigs.update(EXTRA_SIGNATURES)
+    for name, argtypes in sigs.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            if name in SIGNATURES:
+                raise RuntimeError(f"librtv_hip.so does not export {name}")
+            continue
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().rtv_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (status {status}): {msg}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,411 @@
+// HBM-bound fused elementwise kernels of the DiT block: LayerNorm+AdaLN modulation, RMSNorm,
+// RMSNorm(q,k)+3-axis RoPE+KV-cache write, modulation tables, sinusoidal embedding, (un)patchify.
+// One 256-thread workgroup per token row; every access is a 16-byte (8 x bf16) vector.
+// bf16 rounding points follow the reference's eager chains (cited per kernel in include/rtv_hip.h).
+#include "rtv_common.h"
+#include "rtv_internal.h"
+
+namespace rtv {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAXC = 4;  // up to 4 x 8 elements per thread -> d <= 8192
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from the previous use
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[w] = a;
+    red[4 + w] = b;
+  }
+  __syncthreads();
+  a = red[0] + red[1] + red[2] + red[3];
+  b = red[4] + red[5] + red[6] + red[7];
+}
+
+// ------------------------------------------------------------------ LayerNorm (+ modulation)
+__global__ __launch_bounds__(EW_THREADS) void layernorm_modulate_kernel(
+    const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int d, float eps,
+    const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale, int frame_stride,
+    int rows_per_frame, const bf16_t* __restrict__ weight, const bf16_t* __restrict__ bias) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int nchunks = d >> 3;
+  const bf16_t* xr = x + (size_t)row * d;
+  float v[EW_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      u32x4 raw = *(const u32x4*)(xr + c * 8);
+      unpack_bf16x8(raw, v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j];
+    }
+  }
+  const float mean = block_sum(s, red) / (float)d;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = v[i][j] - mean;
+        s2 += t * t;
+      }
+    }
+  }
+  const float var = block_sum(s2, red) / (float)d;
+  const float rstd = rsqrtf(var + eps);
+  const int f = rows_per_frame > 0 ? row / rows_per_frame : 0;
+  const bf16_t* sh = shift ? shift + (size_t)f * frame_stride : nullptr;
+  const bf16_t* sc = scale ? scale + (size_t)f * frame_stride : nullptr;
+  bf16_t* orow = out + (size_t)row * d;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      float o[8];
+      if (weight) {  // affine LayerNorm: one rounding at the output (torch kernel computes in f32)
+        float w8[8], b8[8];
+        unpack_bf16x8(*(const u32x4*)(weight + c * 8), w8);
+        unpack_bf16x8(*(const u32x4*)(bias + c * 8), b8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * w8[j] + b8[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd;
+        if (sc) {  // bf16(bf16(bf16(ln) * bf16(1 + scale)) + shift)
+          float sc8[8], sh8[8];
+          unpack_bf16x8(*(const u32x4*)(sc + c * 8), sc8);
+          unpack_bf16x8(*(const u32x4*)(sh + c * 8), sh8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float n = round_bf16(o[j]);
+            float a = round_bf16(1.0f + sc8[j]);
+            float p = round_bf16(n * a);
+            o[j] = p + sh8[j];
+          }
+        }
+      }
+      *(u32x4*)(orow + c * 8) = pack_bf16x8(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm over the full channel dim
+__global__ __launch_bounds__(EW_THREADS) void rmsnorm_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                             bf16_t* __restrict__ out, int ldo, int d,
+                                                             float eps,
+                                                             const bf16_t* __restrict__ weight) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int nchunks = d >> 3;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  float v[EW_MAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      unpack_bf16x8(*(const u32x4*)(xr + c * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[i][j] * v[i][j];
+    }
+  }
+  const float r = rsqrtf(block_sum(s, red) / (float)d + eps);
+  bf16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      float w8[8], o[8];
+      unpack_bf16x8(*(const u32x4*)(weight + c * 8), w8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = round_bf16(v[i][j] * r) * w8[j];
+      *(u32x4*)(orow + c * 8) = pack_bf16x8(o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RMSNorm(q,k) + RoPE + KV-cache write
+struct RopeArgs {
+  const bf16_t* qkv;
+  bf16_t* q_out;
+  bf16_t* k_cache;
+  bf16_t* v_cache;
+  int64_t cache_row_stride;
+  int cache_row0;
+  int d, hd;
+  float eps;
+  const bf16_t* wq;
+  const bf16_t* wk;
+  const float2* rope_cs;  // [1024][hd/2]
+  int gh, gw, start_frame;
+};
+
+__device__ __forceinline__ void rope8(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
+                                      int pos_w, const float2* __restrict__ cs) {
+  const int half = hd >> 1;
+  const int pj0 = (col % hd) >> 1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int pj = pj0 + t;
+    int pos = pj < c0 ? pos_f : (pj < c0 + c1 ? pos_h : pos_w);
+    float2 w = cs[pos * half + pj];
+    float a = x[2 * t], b = x[2 * t + 1];
+    x[2 * t] = a * w.x - b * w.y;
+    x[2 * t + 1] = a * w.y + b * w.x;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs a) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const int d = a.d;
+  const int nchunks = d >> 3;
+  const bf16_t* qr = a.qkv + (size_t)row * 3 * d;
+  const bf16_t* kr = qr + d;
+  const bf16_t* vr = kr + d;
+  float q[EW_MAXC][8], k[EW_MAXC][8];
+  u32x4 vraw[EW_MAXC];
+  float sq = 0.f, sk = 0.f;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      unpack_bf16x8(*(const u32x4*)(qr + c * 8), q[i]);
+      unpack_bf16x8(*(const u32x4*)(kr + c * 8), k[i]);
+      vraw[i] = *(const u32x4*)(vr + c * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sq += q[i][j] * q[i][j];
+        sk += k[i][j] * k[i][j];
+      }
+    }
+  }
+  block_sum2(sq, sk, red);
+  const float rq = rsqrtf(sq / (float)d + a.eps);
+  const float rk = rsqrtf(sk / (float)d + a.eps);
+
+  const int half = a.hd >> 1;
+  const int c1 = half / 3, c0 = half - 2 * c1;
+  const int per_frame = a.gh * a.gw;
+  const int f = row / per_frame;
+  const int rem = row - f * per_frame;
+  const int pos_h = rem / a.gw, pos_w = rem - pos_h * a.gw;
+  const int pos_f = a.start_frame + f;
+
+  bf16_t* qo = a.q_out + (size_t)row * d;
+  bf16_t* ko = a.k_cache + (size_t)(a.cache_row0 + row) * a.cache_row_stride;
+  bf16_t* vo = a.v_cache + (size_t)(a.cache_row0 + row) * a.cache_row_stride;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      float wq8[8], wk8[8];
+      unpack_bf16x8(*(const u32x4*)(a.wq + c * 8), wq8);
+      unpack_bf16x8(*(const u32x4*)(a.wk + c * 8), wk8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        q[i][j] = round_bf16(round_bf16(q[i][j] * rq) * wq8[j]);
+        k[i][j] = round_bf16(round_bf16(k[i][j] * rk) * wk8[j]);
+      }
+      rope8(q[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
+      rope8(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
+      *(u32x4*)(qo + c * 8) = pack_bf16x8(q[i]);
+      *(u32x4*)(ko + c * 8) = pack_bf16x8(k[i]);
+      *(u32x4*)(vo + c * 8) = vraw[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ small per-forward tables
+__global__ void modulation_table_kernel(const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e0,
+                                        bf16_t* __restrict__ emod, int L, int F, int J, int J0, int d) {
+  size_t total = (size_t)L * F * J * d;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % d);
+    size_t t = i / d;
+    int j = (int)(t % J);
+    t /= J;
+    int f = (int)(t % F);
+    int l = (int)(t / F);
+    float m = bf16_to_f32(mod[((size_t)l * J + j) * d + c]);
+    float e = bf16_to_f32(e0[((size_t)f * J0 + (J0 == 1 ? 0 : j)) * d + c]);
+    emod[i] = f32_to_bf16(m + e);
+  }
+}
+
+__global__ void sinusoidal_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int F, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int half = dim / 2;
+  if (i >= F * half) return;
+  int f = i / half, c = i % half;
+  double pos = (double)t[f];
+  double w = pow(10000.0, -((double)c / (double)half));
+  double ang = pos * w;
+  out[(size_t)f * dim + c] = f32_to_bf16((float)cos(ang));
+  out[(size_t)f * dim + half + c] = f32_to_bf16((float)sin(ang));
+}
+
+__global__ void patchify_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ rows, int C, int F,
+                                int gh, int gw) {
+  // rows[m][c*4 + p*2 + q] = x[c][f][2h+p][2w+q]
+  size_t total = (size_t)F * gh * gw * C * 4;
+  const int Hh = 2 * gh, Ww = 2 * gw;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int kq = (int)(i % (C * 4));
+    size_t m = i / (C * 4);
+    int c = kq >> 2, p = (kq >> 1) & 1, q = kq & 1;
+    int w = (int)(m % gw);
+    size_t t = m / gw;
+    int h = (int)(t % gh);
+    int f = (int)(t / gh);
+    rows[i] = x[(((size_t)c * F + f) * Hh + 2 * h + p) * Ww + 2 * w + q];
+  }
+}
+
+__global__ void unpatchify_kernel(const bf16_t* __restrict__ rows, bf16_t* __restrict__ x, int C, int F,
+                                  int gh, int gw) {
+  // x[c][f][2h+q][2w+r] = rows[m][(q*2+r)*C + c]
+  const int Hh = 2 * gh, Ww = 2 * gw;
+  size_t total = (size_t)C * F * Hh * Ww;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    int xw = (int)(i % Ww);
+    size_t t = i / Ww;
+    int xh = (int)(t % Hh);
+    t /= Hh;
+    int f = (int)(t % F);
+    int c = (int)(t / F);
+    int h = xh >> 1, q = xh & 1, w = xw >> 1, r = xw & 1;
+    size_t m = ((size_t)f * gh + h) * gw + w;
+    x[i] = rows[m * (C * 4) + (q * 2 + r) * C + c];
+  }
+}
+
+}  // namespace rtv
+
+using namespace rtv;
+
+extern "C" {
+
+int rtv_layernorm_modulate(const void* x, void* out, int M, int d, float eps, const void* shift,
+                           const void* scale, int frame_stride, int rows_per_frame, const void* weight,
+                           const void* bias, rtv_stream_t stream) {
+  if (M <= 0) return 0;
+  if (d % 8 || d > EW_THREADS * 8 * EW_MAXC) return set_error(-1, "layernorm_modulate: d must be a multiple of 8 and <= 8192");
+  if ((shift == nullptr) != (scale == nullptr)) return set_error(-1, "layernorm_modulate: shift and scale go together");
+  if ((weight == nullptr) != (bias == nullptr)) return set_error(-1, "layernorm_modulate: weight and bias go together");
+  if (weight && scale) return set_error(-1, "layernorm_modulate: affine and modulation are exclusive");
+  if (scale && (rows_per_frame <= 0 || frame_stride % 8)) return set_error(-1, "layernorm_modulate: bad frame geometry");
+  ProfScope prof(PROF_LN, (hipStream_t)stream, 2.0 * M * d * 2);
+  hipLaunchKernelGGL(layernorm_modulate_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (bf16_t*)out, d, eps, (const bf16_t*)shift, (const bf16_t*)scale,
+                     frame_stride, rows_per_frame, (const bf16_t*)weight, (const bf16_t*)bias);
+  return check_launch("layernorm_modulate");
+}
+
+int rtv_rmsnorm(const void* x, int ldx, void* out, int ldo, int M, int d, float eps, const void* weight,
+                rtv_stream_t stream) {
+  if (M <= 0) return 0;
+  if (d % 8 || d > EW_THREADS * 8 * EW_MAXC || ldx % 8 || ldo % 8)
+    return set_error(-1, "rmsnorm: d/ld must be multiples of 8, d <= 8192");
+  if (!weight) return set_error(-1, "rmsnorm: weight required");
+  ProfScope prof(PROF_LN, (hipStream_t)stream, 2.0 * M * d * 2);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     ldx, (bf16_t*)out, ldo, d, eps, (const bf16_t*)weight);
+  return check_launch("rmsnorm");
+}
+
+int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_cache,
+                           int64_t cache_row_stride, int cache_row0, int M, int d, int num_heads, float eps,
+                           const void* wq, const void* wk, const void* rope_cs, int F, int gh, int gw,
+                           int start_frame, rtv_stream_t stream) {
+  if (M <= 0) return 0;
+  if (num_heads <= 0 || d % num_heads) return set_error(-1, "qk_norm_rope_cache: d % num_heads != 0");
+  const int hd = d / num_heads;
+  if (d % 8 || d > EW_THREADS * 8 * EW_MAXC || hd % 8 || cache_row_stride % 8)
+    return set_error(-1, "qk_norm_rope_cache: alignment (d, head_dim, cache stride multiples of 8; d <= 8192)");
+  if (M != F * gh * gw) return set_error(-1, "qk_norm_rope_cache: M != F*gh*gw");
+  if (start_frame < 0 || start_frame + F > 1024 || gh > 1024 || gw > 1024)
+    return set_error(-1, "qk_norm_rope_cache: position exceeds the 1024-entry RoPE table");
+  if (cache_row0 < 0) return set_error(-1, "qk_norm_rope_cache: negative cache row");
+  RopeArgs a;
+  a.qkv = (const bf16_t*)qkv;
+  a.q_out = (bf16_t*)q_out;
+  a.k_cache = (bf16_t*)k_cache;
+  a.v_cache = (bf16_t*)v_cache;
+  a.cache_row_stride = cache_row_stride;
+  a.cache_row0 = cache_row0;
+  a.d = d;
+  a.hd = hd;
+  a.eps = eps;
+  a.wq = (const bf16_t*)wq;
+  a.wk = (const bf16_t*)wk;
+  a.rope_cs = (const float2*)rope_cs;
+  a.gh = gh;
+  a.gw = gw;
+  a.start_frame = start_frame;
+  ProfScope prof(PROF_ROPE, (hipStream_t)stream, 6.0 * M * d * 2);
+  hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("qk_norm_rope_cache");
+}
+
+int rtv_modulation_table(const void* modulation, const void* e0, void* emod, int L, int F, int J, int J0,
+                         int d, rtv_stream_t stream) {
+  if (J0 != J && J0 != 1) return set_error(-1, "modulation_table: J0 must be J or 1");
+  size_t total = (size_t)L * F * J * d;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  ProfScope prof(PROF_MISC, (hipStream_t)stream, (double)total * 6);
+  hipLaunchKernelGGL(modulation_table_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)modulation, (const bf16_t*)e0, (bf16_t*)emod, L, F, J, J0, d);
+  return check_launch("modulation_table");
+}
+
+int rtv_sinusoidal_embedding(const void* t, void* out, int F, int dim, rtv_stream_t stream) {
+  if (dim % 2) return set_error(-1, "sinusoidal_embedding: dim must be even");
+  int n = F * (dim / 2);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sinusoidal_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+                     (const float*)t, (bf16_t*)out, F, dim);
+  return check_launch("sinusoidal_embedding");
+}
+
+int rtv_patchify(const void* x, void* rows, int C, int F, int gh, int gw, rtv_stream_t stream) {
+  size_t total = (size_t)F * gh * gw * C * 4;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)rows, C, F, gh, gw);
+  return check_launch("patchify");
+}
+
+int rtv_unpatchify(const void* rows, void* x, int C, int F, int gh, int gw, rtv_stream_t stream) {
+  size_t total = (size_t)F * gh * gw * C * 4;
+  if (total == 0) return 0;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)rows, (bf16_t*)x, C, F, gh, gw);
+  return check_launch("unpatchify");
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// Dense projection GEMM for the DiT block (QKV / O / cross-q / cross-o / FFN / embeddings / head).
+// See gemm_core.h for the tile structure.
+#include "gemm_core.h"
+#include "rtv_internal.h"
+
+namespace rtv {
+
+template <bool F16, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
+  typedef TileCfg<BM, BN, BK, WM, WN> Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- workgroup -> output tile (XCD-contiguous chunks, then GROUP_M x tiles_n supertiles so the
+  //      tiles that run concurrently on one XCD share A and W panels through its L2)
+  const int nwg = p.tiles_m * p.tiles_n;
+  int id = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = id / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = id - group * per_group;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-lane DMA source offsets (elements), K offset 0
+  const int cpos = lane % Cfg::CH;   // chunk slot this lane fills in LDS
+  const int rsub = lane / Cfg::CH;   // row inside the 64-lane DMA group
+  uint32_t a_off[Cfg::A_INST], b_off[Cfg::B_INST];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_INST; ++i) {
+    int row = (wave * Cfg::A_INST + i) * Cfg::RPI + rsub;
+    int gm_row = min(m0 + row, p.M - 1);
+    a_off[i] = (uint32_t)gm_row * (uint32_t)p.lda + Cfg::swz(row, cpos) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_INST; ++i) {
+    int row = (wave * Cfg::B_INST + i) * Cfg::RPI + rsub;
+    int gn_row = min(n0 + row, p.N - 1);
+    b_off[i] = (uint32_t)gn_row * (uint32_t)p.ldw + Cfg::swz(row, cpos) * 8;
+  }
+
+  auto stage = [&](int kt, int buf) {
+    char* sA = smem + buf * Cfg::STAGE_BYTES;
+    char* sB = sA + Cfg::A_BYTES;
+    const uint16_t* Ak = p.A + (size_t)kt * BK;
+    const uint16_t* Wk = p.W + (size_t)kt * BK;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_INST; ++i)
+      dma16(Ak + a_off[i], sA + (wave * Cfg::A_INST + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < Cfg::B_INST; ++i)
+      dma16(Wk + b_off[i], sB + (wave * Cfg::B_INST + i) * 1024);
+  };
+
+  f32x16 acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+  for (int mi = 0; mi < Cfg::TM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < Cfg::TN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    // tile kt has landed (every wave drains its own DMA before the barrier) and every wave is done
+    // reading buf^1 (it was consumed in iteration kt-1)
+    __syncthreads();
+    if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+    const char* sA = smem + buf * Cfg::STAGE_BYTES;
+    mma_stage<F16, Cfg, BK>(sA, sA + Cfg::A_BYTES, a_row0, b_row0, lane, acc);
+  }
+
+  store_tile<F16, Cfg>(p, m0 + a_row0, n0 + b_row0, lane, acc);
+}
+
+template <bool F16, int BM, int BN, int BK, int WM, int WN>
+static int launch_cfg(GemmParams p, hipStream_t stream) {
+  typedef TileCfg<BM, BN, BK, WM, WN> Cfg;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  auto kern = gemm_kernel<F16, BM, BN, BK, WM, WN>;
+  static bool attr_set = false;
+  const int lds = 2 * Cfg::STAGE_BYTES;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return set_error(e, "gemm: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  ProfScope prof(PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
+  return check_launch("gemm");
+}
+
+int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0 || p.K <= 0) return set_error(-1, "gemm: empty problem");
+  if (p.K % 64 != 0) return set_error(-1, "gemm: K must be a multiple of 64");
+  if (p.N % 8 != 0) return set_error(-1, "gemm: N must be a multiple of 8");
+  if ((p.lda % 8) || (p.ldw % 8) || (p.ldc % 4) || (p.residual && (p.ldr % 4)))
+    return set_error(-1, "gemm: leading dimensions must keep 16-byte (A,W) / 8-byte (C,res) alignment");
+  if (p.gate && p.rows_per_frame <= 0) return set_error(-1, "gemm: gate needs rows_per_frame");
+  const bool f16 = dtype == RTV_DTYPE_F16;
+  if (dtype != RTV_DTYPE_BF16 && dtype != RTV_DTYPE_F16) return set_error(-1, "gemm: dtype");
+  switch (tile_cfg) {
+    case 0:
+    case 1:
+      return f16 ? launch_cfg<true, 128, 128, 64, 2, 2>(p, stream)
+                 : launch_cfg<false, 128, 128, 64, 2, 2>(p, stream);
+    case 2:
+      return f16 ? launch_cfg<true, 256, 128, 64, 4, 2>(p, stream)
+                 : launch_cfg<false, 256, 128, 64, 4, 2>(p, stream);
+    case 3:
+      return f16 ? launch_cfg<true, 256, 256, 64, 2, 4>(p, stream)
+                 : launch_cfg<false, 256, 256, 64, 2, 4>(p, stream);
+    default:
+      return set_error(-1, "gemm: unknown tile config");
+  }
+}
+
+}  // namespace rtv

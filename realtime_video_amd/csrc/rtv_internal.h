@@ -1,0 +1,25 @@
+// Host-side internals shared by the launchers: error state, launch checks, event profiling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/rtv_hip.h"
+
+namespace rtv {
+
+int set_error(int code, const char* msg);  // records message, returns code (never 0)
+int check_launch(const char* what);        // hipGetLastError -> set_error
+
+enum ProfClass { PROF_GEMM = 0, PROF_ATTN, PROF_LN, PROF_ROPE, PROF_CONV, PROF_MISC, PROF_NCLASS };
+
+// Brackets one kernel launch with hipEvents on its stream when profiling is enabled
+// (rtv_prof_enable); otherwise free.
+struct ProfScope {
+  ProfScope(int cls, hipStream_t stream, double work);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
+struct GemmParams;
+int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream);
+
+}  // namespace rtv

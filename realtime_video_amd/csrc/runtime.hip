@@ -1,0 +1,144 @@
+// Library runtime: error state, launch checks, hipEvent kernel-class profiling, C-ABI GEMM entry.
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "gemm_core.h"
+#include "rtv_internal.h"
+
+namespace rtv {
+
+static thread_local std::string g_err;
+
+int set_error(int code, const char* msg) {
+  g_err = msg ? msg : "unknown error";
+  if (code > 0) {
+    g_err += ": ";
+    g_err += hipGetErrorString((hipError_t)code);
+  }
+  return code == 0 ? -1 : code;
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error((int)e, what);
+  return 0;
+}
+
+// ---------------------------------------------------------------- profiling
+struct ProfRec {
+  int cls;
+  hipEvent_t start, stop;
+  double work;
+};
+static bool g_prof_on = false;
+static std::mutex g_prof_mu;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t get_event() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+ProfScope::ProfScope(int cls, hipStream_t s, double work) : slot(-1), stream(s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r;
+  r.cls = cls;
+  r.work = work;
+  r.start = get_event();
+  r.stop = get_event();
+  hipEventRecord(r.start, s);
+  g_prof.push_back(r);
+  slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  hipEventRecord(g_prof[slot].stop, stream);
+}
+
+}  // namespace rtv
+
+using namespace rtv;
+
+extern "C" {
+
+int rtv_version(void) { return 100; }
+
+const char* rtv_last_error(void) { return g_err.c_str(); }
+
+int rtv_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+int rtv_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) {
+    g_event_pool.push_back(r.start);
+    g_event_pool.push_back(r.stop);
+  }
+  g_prof.clear();
+  return 0;
+}
+
+int rtv_prof_read(int cls, double* total_ms, int64_t* launches, double* total_work) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0, work = 0;
+  int64_t n = 0;
+  for (auto& r : g_prof) {
+    if (r.cls != cls) continue;
+    hipError_t e = hipEventSynchronize(r.stop);
+    if (e != hipSuccess) return set_error((int)e, "prof_read: hipEventSynchronize");
+    float t = 0;
+    e = hipEventElapsedTime(&t, r.start, r.stop);
+    if (e != hipSuccess) return set_error((int)e, "prof_read: hipEventElapsedTime");
+    ms += t;
+    work += r.work;
+    ++n;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (total_work) *total_work = work;
+  return 0;
+}
+
+int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
+             const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame,
+             const void* residual, int ldr, int dtype, int tile_cfg, rtv_stream_t stream) {
+  if (!A || !W || !C) return set_error(-1, "gemm: null operand");
+  if (((uintptr_t)A | (uintptr_t)W) & 15) return set_error(-1, "gemm: A/W must be 16-byte aligned");
+  if (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)gate | (uintptr_t)residual) & 7)
+    return set_error(-1, "gemm: C/bias/gate/residual must be 8-byte aligned");
+  if (gate && (gate_stride % 4)) return set_error(-1, "gemm: gate_stride must be a multiple of 4");
+  if (act < 0 || act > 2) return set_error(-1, "gemm: unknown activation");
+  GemmParams p;
+  p.A = (const uint16_t*)A;
+  p.W = (const uint16_t*)W;
+  p.C = (uint16_t*)C;
+  p.lda = lda;
+  p.ldw = ldw;
+  p.ldc = ldc;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.bias = (const uint16_t*)bias;
+  p.act = act;
+  p.gate = (const uint16_t*)gate;
+  p.gate_stride = gate_stride;
+  p.rows_per_frame = rows_per_frame;
+  p.residual = (const uint16_t*)residual;
+  p.ldr = ldr;
+  p.tiles_m = p.tiles_n = 0;
+  return launch_gemm(p, dtype, tile_cfg, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Thin tensor-level wrappers over the C-ABI kernels (device pointers + sizes + current HIP stream).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic happens in
+librtv_hip.so.  Every wrapper refuses non-GPU tensors (no CPU fallback).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_GELU_TANH, ACT_SILU = 0, 1, 2
+DT_BF16, DT_F16 = 0, 1
+PROF_CLASSES = {"gemm": 0, "attn": 1, "layernorm": 2, "rope": 3, "conv": 4, "misc": 5}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype == torch.float16:
+        return DT_F16
+    raise TypeError(f"expected bfloat16 or float16 tensor, got {t.dtype}")
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("realtime_video_amd kernels need GPU tensors (no CPU fallback)")
+
+
+# --------------------------------------------------------------------------------------- profiling
+def prof_enable(on=True):
+    _lib.call("rtv_prof_enable", int(bool(on)))
+
+
+def prof_reset():
+    _lib.call("rtv_prof_reset")
+
+
+def prof_read(cls):
+    ms, n, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.call("rtv_prof_read", PROF_CLASSES[cls] if isinstance(cls, str) else int(cls),
+              ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work))
+    return {"ms": ms.value, "launches": n.value, "work": work.value}
+
+
+# --------------------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, out=None, scale=None, causal_block=0, q_offset=0):
+    """softmax(scale q k^T) v.  q:[B,Lq,H,128], k/v:[B,Lkv,H,128] (strided views allowed as long as
+    the last two dims are dense), returns [B,Lq,H,128] contiguous."""
+    _gpu(q, k, v)
+    B, Lq, H, D = q.shape
+    Lkv = k.shape[1]
+    if k.shape != v.shape or k.shape[0] != B or k.shape[2] != H or k.shape[3] != D:
+        raise ValueError(f"attention shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if not (q.dtype == k.dtype == v.dtype):
+        raise TypeError("q, k, v must share a dtype")
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("attention operands need dense [H, D] inner dims (BLHD layout)")
+    if out is None:
+        out = torch.empty((B, Lq, H, D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    _lib.call("rtv_attn_fwd", _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Lq, Lkv, H, D,
+              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+              out.stride(0), out.stride(1), float(scale), int(causal_block), int(q_offset), _dt(q), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------- GEMM
+def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame=0, residual=None,
+         out=None, tile_cfg=0):
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T) — nn.Linear with fused bias/activation/gate/residual."""
+    _gpu(a, w, bias, gate, residual, out)
+    if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[1]:
+        raise ValueError(f"gemm shape mismatch a{tuple(a.shape)} w{tuple(w.shape)}")
+    if a.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError("gemm operands must be K-contiguous")
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    _lib.call("rtv_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K,
+              _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame),
+              _ptr(residual), residual.stride(0) if residual is not None else 0,
+              _dt(a), int(tile_cfg), _stream())
+    return out
+
+
+# --------------------------------------------------------------------------------------- norms
+def layernorm_modulate(x, eps=1e-6, shift=None, scale=None, frame_stride=0, rows_per_frame=0,
+                       weight=None, bias=None, out=None):
+    """LN(x) [* (1+scale[f]) + shift[f]]  or affine LN.  x:[M,d] bf16."""
+    _gpu(x, shift, scale, weight, bias)
+    M, d = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("rtv_layernorm_modulate", _ptr(x), _ptr(out), M, d, float(eps), _ptr(shift), _ptr(scale),
+              int(frame_stride), int(rows_per_frame), _ptr(weight), _ptr(bias), _stream())
+    return out
+
+
+def rmsnorm(x, weight, eps=1e-6, out=None):
+    _gpu(x, weight)
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=x.dtype, device=x.device)
+    _lib.call("rtv_rmsnorm", _ptr(x), x.stride(0), _ptr(out), out.stride(0), M, d, float(eps), _ptr(weight),
+              _stream())
+    return out
+
+
+def qk_norm_rope_cache(qkv, k_cache, v_cache, cache_row0, num_heads, wq, wk, rope_cs, grid, start_frame,
+                       eps=1e-6, q_out=None):
+    """qkv:[M,3d]; k_cache/v_cache:[kv_size,H,hd] views (row stride = stride(0)); grid=(F,gh,gw)."""
+    _gpu(qkv, k_cache, v_cache, wq, wk, rope_cs)
+    M, d3 = qkv.shape
+    d = d3 // 3
+    F, gh, gw = grid
+    if q_out is None:
+        q_out = torch.empty((M, d), dtype=qkv.dtype, device=qkv.device)
+    if cache_row0 + M > k_cache.shape[0]:
+        raise ValueError("KV-cache write out of range")
+    _lib.call("rtv_qk_norm_rope_cache", _ptr(qkv), _ptr(q_out), _ptr(k_cache), _ptr(v_cache),
+              k_cache.stride(0), int(cache_row0), M, d, int(num_heads), float(eps), _ptr(wq), _ptr(wk),
+              _ptr(rope_cs), int(F), int(gh), int(gw), int(start_frame), _stream())
+    return q_out
+
+
+def modulation_table(modulation, e0, out=None):
+    """modulation:[L,J,d], e0:[F,J0,d] -> [L,F,J,d] = bf16(modulation + e0)."""
+    _gpu(modulation, e0)
+    L, J, d = modulation.shape
+    F, J0, _ = e0.shape
+    if out is None:
+        out = torch.empty((L, F, J, d), dtype=modulation.dtype, device=modulation.device)
+    _lib.call("rtv_modulation_table", _ptr(modulation), _ptr(e0), _ptr(out), L, F, J, J0, d, _stream())
+    return out
+
+
+def sinusoidal_embedding(t, dim):
+    _gpu(t)
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty((t.numel(), dim), dtype=torch.bfloat16, device=t.device)
+    _lib.call("rtv_sinusoidal_embedding", _ptr(t), _ptr(out), t.numel(), int(dim), _stream())
+    return out
+
+
+def patchify(x, gh, gw):
+    """x:[C,F,2gh,2gw] -> [F*gh*gw, C*4]"""
+    _gpu(x)
+    C, F = x.shape[0], x.shape[1]
+    x = x.contiguous()
+    out = torch.empty((F * gh * gw, C * 4), dtype=x.dtype, device=x.device)
+    _lib.call("rtv_patchify", _ptr(x), _ptr(out), C, F, gh, gw, _stream())
+    return out
+
+
+def unpatchify(rows, C, F, gh, gw):
+    _gpu(rows)
+    rows = rows.contiguous()
+    out = torch.empty((C, F, 2 * gh, 2 * gw), dtype=rows.dtype, device=rows.device)
+    _lib.call("rtv_unpatchify", _ptr(rows), _ptr(out), C, F, gh, gw, _stream())
+    return out

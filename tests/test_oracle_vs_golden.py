@@ -1,0 +1,127 @@
+"""Pins the CPU oracle (oracle/wan_oracle.py) against golden vectors minted from the upstream
+reference's own modules (oracle/make_golden.py).  CPU only."""
+import os
+import sys
+
+import torch
+
+from conftest import max_abs, rel_l2
+
+from oracle import wan_oracle as wo
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle.make_golden import TEXT_DIM, TINY, cache_sample, fresh_caches, tiny_inputs  # noqa: E402
+
+BF16_EPS = 2 ** -8
+
+
+def test_attention_sdpa_matches_reference(golden):
+    g = golden("ops.pt")
+    out = wo.attention_sdpa(g["attn_q"], g["attn_k"], g["attn_v"])
+    assert out.dtype == torch.bfloat16 and out.is_contiguous()
+    assert max_abs(out, g["attn_out"]) <= 2e-2
+    gold = wo.attention_math(g["attn_q"], g["attn_k"], g["attn_v"])
+    assert max_abs(g["attn_out"], gold) <= 2e-2  # the reference itself vs the fp32 definition
+
+
+def test_rope_matches_reference(golden):
+    g = golden("ops.pt")
+    freqs = wo.rope_table(128)
+    assert torch.equal(torch.view_as_real(freqs[[0, 1, 5, 100, 1023]]), g["freqs_sample"])
+    assert torch.equal(wo.rope_apply(g["rope_x"], (2, 6, 8), freqs, start_frame=3), g["rope_causal_s3"])
+    assert torch.equal(wo.rope_apply(g["rope_x"], (2, 6, 8), freqs), g["rope_s0"])
+
+
+def test_norms_match_reference(golden):
+    g = golden("ops.pt")
+    assert torch.equal(wo.rms_norm(g["norm_x"], g["norm_w"]), g["rms"])
+    assert max_abs(wo.layer_norm(g["norm_x"]), g["ln"]) <= 2 * BF16_EPS * 4
+
+
+def test_scheduler_matches_reference(golden):
+    g = golden("ops.pt")
+    s = wo.FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    assert torch.equal(s.timesteps, g["sched_timesteps"])
+    assert torch.equal(s.sigmas, g["sched_sigmas"])
+    zp = torch.cat((s.timesteps, torch.tensor([0], dtype=torch.float32)))
+    assert torch.equal(wo.get_denoising_schedule(zp, 1.0, 4), g["schedule_4"])
+    assert torch.equal(wo.get_denoising_schedule(zp, 1.0, 5), g["schedule_5"])
+    assert torch.equal(wo.get_denoising_schedule(zp, 0.7, 4), g["schedule_4_s07"])
+    # headline schedule: 4 steps, shift 5 -> [1000, 908.8, 714.0, 0]
+    assert [round(float(v), 1) for v in g["schedule_4"]] == [1000.0, 908.8, 714.0, 0.0]
+    assert torch.equal(s.add_noise(g["an_x0"], g["an_noise"], g["an_t"]), g["an_out"])
+    assert torch.equal(wo.convert_flow_pred_to_x0(s, g["an_x0"], g["an_noise"], g["an_t"].float()), g["x0_out"])
+    assert torch.equal(wo.sinusoidal_embedding_1d(256, g["schedule_4"]), g["sinus"])
+
+
+def _check_cache(sample, gold, tol):
+    for c, gc in zip(sample, gold):
+        assert c["global_end_index"] == gc["global_end_index"]
+        assert c["local_end_index"] == gc["local_end_index"]
+        # rows that must be zero (never written) are exactly zero in both
+        assert torch.equal(c["k"] == 0, gc["k"] == 0)
+        assert rel_l2(c["k"], gc["k"]) <= tol and rel_l2(c["v"], gc["v"]) <= tol
+
+
+def test_dit_server_path_matches_reference(golden):
+    """recompute + denoise sequence of SURVEY.md Appendix B on the tiny model, bf16 on CPU."""
+    g = golden("dit_server_path.pt")
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    assert abs(float(sum(v.double().abs().sum() for v in w.values())) - g["weights_checksum"]) < 1e-6 * g["weights_checksum"]
+    lat, ctx = tiny_inputs()
+    kv, ca = fresh_caches(cfg, 9360)
+    sched = wo.FlowMatchScheduler()
+    steps = g["steps"]
+    tol = 1e-2
+
+    def ts(v):
+        return torch.ones([1, 3], dtype=torch.int64) * v
+
+    flow, x0 = wo.wrapper_forward(w, cfg, sched, lat[0], [ctx], ts(steps[0]), kv, ca, 0)
+    assert rel_l2(flow, g["b0s0_flow"]) <= tol and rel_l2(x0, g["b0s0_x0"]) <= tol
+    _check_cache(cache_sample(kv), g["b0s0_cache"], tol)
+    flow, _ = wo.wrapper_forward(w, cfg, sched, lat[1], [ctx], ts(steps[1]), kv, ca, 0)
+    assert rel_l2(flow, g["b0s1_flow"]) <= tol
+    _check_cache(cache_sample(kv), g["b0s1_cache"], tol)
+    wo.reset_kv_cache(kv)
+    flow, _ = wo.wrapper_forward(w, cfg, sched, lat[2], [ctx], torch.zeros([1, 3], dtype=torch.int64), kv, ca,
+                                 3 * 1560, recompute=True)
+    assert rel_l2(flow, g["rc_flow"]) <= tol
+    _check_cache(cache_sample(kv), g["rc_cache"], tol)
+    flow, x0 = wo.wrapper_forward(w, cfg, sched, lat[3], [ctx], ts(steps[0]), kv, ca, 4680)
+    assert rel_l2(flow, g["b1s0_flow"]) <= tol and rel_l2(x0, g["b1s0_x0"]) <= tol
+    _check_cache(cache_sample(kv), g["b1s0_cache"], tol)
+    assert kv[0]["local_end_index"] == 9360 and kv[0]["global_end_index"] == 9360
+
+
+def test_dit_rolling_cache_matches_reference(golden):
+    g = golden("dit_rolling.pt")
+    cfg = dict(TINY, local_attn_size=6, sink_size=1, num_layers=1)
+    w = wo.make_weights(cfg, seed=3, text_dim=TEXT_DIM)
+    lat, ctx = tiny_inputs(seed=7)
+    kv, ca = fresh_caches(cfg, 6 * 1560)
+    sched = wo.FlowMatchScheduler()
+    idx = []
+    for b in range(4):
+        t = torch.ones([1, 3], dtype=torch.int64) * 500
+        flow, _ = wo.wrapper_forward(w, cfg, sched, lat[b], [ctx], t, kv, ca, b * 4680)
+        idx.append((kv[0]["global_end_index"], kv[0]["local_end_index"]))
+        assert rel_l2(flow[0, :, :, ::3, ::4], g["flow_sample"][b]) <= 1e-2
+    assert idx == g["indices"] == [(4680, 4680), (9360, 9360), (14040, 9360), (18720, 9360)]
+    _check_cache(cache_sample(kv), g["cache"], 1e-2)
+
+
+def test_gold_fp32_graph_bounds_bf16_error(golden):
+    """The fp32 restatement of the same graph is the 'gold' used to state tolerances."""
+    g = golden("dit_server_path.pt")
+    cfg = dict(TINY)
+    w = {k: v.float() for k, v in wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM).items()}
+    lat, ctx = tiny_inputs()
+    kv, ca = fresh_caches(cfg, 9360, dtype=torch.float32)
+    sched = wo.FlowMatchScheduler()
+    t = torch.ones([1, 3], dtype=torch.int64) * g["steps"][0]
+    flow, _ = wo.wrapper_forward(w, cfg, sched, lat[0].float(), [ctx.float()], t, kv, ca, 0,
+                                 attn_fn=lambda q, k, v: wo.attention_sdpa(q, k, v, dtype=None))
+    err = rel_l2(g["b0s0_flow"], flow)
+    assert err <= 2e-2, err  # reference bf16 eager vs fp32 gold
