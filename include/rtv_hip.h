@@ -110,6 +110,72 @@ int rtv_sinusoidal_embedding(const void* t, void* out, int F, int dim, rtv_strea
 int rtv_patchify(const void* x, void* rows, int C, int F, int gh, int gw, rtv_stream_t stream);
 int rtv_unpatchify(const void* rows, void* x, int C, int F, int gh, int gw, rtv_stream_t stream);
 
+/* rtv_silu: out = bf16(silu(x)) elementwise (time_projection's leading nn.SiLU, causal_model.py:622-623). */
+int rtv_silu(const void* x, void* out, int64_t n, rtv_stream_t stream);
+
+/* ---- whole-forward orchestrator: one call = CausalWanModel._forward_inference ------------------
+ * (wan/modules/causal_model.py:825-954 with the block body :440-492, head :495-523, unpatchify
+ * :1126-1149).  The host keeps the reference's python-int cache bookkeeping (global_end_index /
+ * local_end_index, causal_model.py:358-392) and passes the resulting row window; the library owns
+ * no memory: weights, caches and the workspace are caller allocations (torch tensors). */
+typedef struct rtv_dit_config {
+  int dim, ffn_dim, num_heads, num_layers;
+  int freq_dim, text_dim, text_len;
+  int in_dim, out_dim;          /* latent channels (16, 16); patch size is (1,2,2) */
+  float eps;
+} rtv_dit_config;
+
+typedef struct rtv_dit_layer_weights { /* bf16 device pointers, reference state_dict names in comments */
+  const void *qkv_w, *qkv_b;          /* self_attn.{q,k,v} fused [3d,d] (fuse_projections, causal_model.py:203-216) */
+  const void *norm_q_w, *norm_k_w;    /* self_attn.norm_q / norm_k .weight [d] */
+  const void *o_w, *o_b;              /* self_attn.o */
+  const void *norm3_w, *norm3_b;      /* norm3 (affine LayerNorm) */
+  const void *cq_w, *cq_b, *ck_w, *ck_b, *cv_w, *cv_b, *co_w, *co_b; /* cross_attn.{q,k,v,o} */
+  const void *cnorm_q_w, *cnorm_k_w;  /* cross_attn.norm_q / norm_k */
+  const void *ffn0_w, *ffn0_b, *ffn2_w, *ffn2_b; /* ffn.0 / ffn.2 */
+} rtv_dit_layer_weights;
+
+typedef struct rtv_dit_weights {
+  const void *patch_w, *patch_b;      /* patch_embedding [d, in_dim*4] */
+  const void *text0_w, *text0_b, *text2_w, *text2_b;
+  const void *time0_w, *time0_b, *time2_w, *time2_b;
+  const void *tproj_w, *tproj_b;      /* time_projection.1 [6d, d] */
+  const void *head_w, *head_b;        /* head.head [out_dim*4, d] */
+  const void *modulation;             /* blocks.*.modulation packed [L][6][d] */
+  const void *head_modulation;        /* head.modulation [2][d] */
+  const void *rope_cs;                /* float2 [1024][head_dim/2] */
+  const rtv_dit_layer_weights* layers; /* host array [num_layers] */
+} rtv_dit_weights;
+
+typedef struct rtv_dit_step {
+  const void* x;            /* latent [in_dim, F, 2gh, 2gw] bf16 */
+  const void* t;            /* float32 [F] timesteps */
+  const void* context;      /* [text_len, text_dim] bf16 zero-padded prompt embedding; used iff compute_cross_kv */
+  void* out;                /* flow prediction [out_dim, F, 2gh, 2gw] bf16 */
+  int F, gh, gw;            /* token grid: M = F*gh*gw */
+  void* const* kv_k;        /* host arrays [num_layers] of device pointers: KV cache [kv_size][H][hd] */
+  void* const* kv_v;
+  int64_t kv_row_stride;    /* elements between cache rows (H*hd when contiguous) */
+  void* const* ca_k;        /* cross-attention caches [text_len][H][hd] */
+  void* const* ca_v;
+  int compute_cross_kv;     /* crossattn_cache["is_init"] == False (model.py:186-192) */
+  int cache_row0;           /* local_start_index: first cache row written by this call */
+  int kv_lo, kv_hi;         /* attention window over cache rows [kv_lo, kv_hi) (causal_model.py:386-390) */
+  int start_frame;          /* RoPE temporal offset (current_start // 1560, :351-356; 0 for the recompute pass) */
+  int causal_block;         /* 0 = dense; >0 = block-causal recompute pass (tokens per block, :305-348) */
+  int gemm_tile_cfg;        /* 0 = default */
+} rtv_dit_step;
+
+size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw);
+int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step,
+                    void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+
+/* ---- hardware-layout probes (test support; see csrc/probe.hip) --------------------------------- */
+int rtv_probe_mfma(const void* A /*[32][16] bf16*/, const void* B /*[16][32] bf16*/, void* D /*[32][32] f32*/,
+                   rtv_stream_t stream);
+int rtv_probe_tr(const void* V /*[64][128] bf16*/, void* out /*[4][64][8] bf16*/, int kbk, int s,
+                 rtv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

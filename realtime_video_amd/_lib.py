@@ -36,6 +36,8 @@ SIGNATURES = {
     "rtv_sinusoidal_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
     "rtv_patchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "rtv_unpatchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_probe_mfma": [c_vp, c_vp, c_vp, c_vp],
+    "rtv_probe_tr": [c_vp, c_vp, c_int, c_int, c_vp],
 }
 # later sections (DiT forward, VAE) register their signatures here as well
 EXTRA_SIGNATURES = {}
