@@ -1,0 +1,336 @@
+"""Host-side mirror of the reference's `CausalWanModel` (wan/modules/causal_model.py:526-1173) for the
+inference hot path: same constructor arguments, attribute surface and `forward(...)` contract, but the
+forward is ONE call into the native orchestrator `rtv_dit_forward` (include/rtv_hip.h) which sequences
+the hand-written gfx950 kernels.  Python keeps exactly what the reference keeps in Python: the
+integer KV-cache bookkeeping (global_end_index / local_end_index, causal_model.py:358-392).
+
+Surface used by the reference's callers and reproduced here:
+  model.blocks[i].self_attn.{local_attn_size, sink_size, num_frame_per_block, fuse_projections()},
+  model.block_mask, model._prepare_blockwise_causal_attn_mask(...), model.config.{num_heads, dim},
+  model.local_attn_size, model.num_frame_per_block, model(x, t=, context=, seq_len=, kv_cache=,
+  crossattn_cache=, current_start=, cache_start=).
+"""
+import ctypes
+import types
+
+import torch
+
+from . import _lib, ops
+from .rope import rope_cos_sin_table
+
+c_vp = ctypes.c_void_p
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("dim", "ffn_dim", "num_heads", "num_layers", "freq_dim", "text_dim",
+                                            "text_len", "in_dim", "out_dim")] + [("eps", ctypes.c_float)]
+
+
+_LAYER_FIELDS = ("qkv_w", "qkv_b", "norm_q_w", "norm_k_w", "o_w", "o_b", "norm3_w", "norm3_b",
+                 "cq_w", "cq_b", "ck_w", "ck_b", "cv_w", "cv_b", "co_w", "co_b", "cnorm_q_w", "cnorm_k_w",
+                 "ffn0_w", "ffn0_b", "ffn2_w", "ffn2_b")
+
+
+class _LayerW(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in _LAYER_FIELDS]
+
+
+_TOP_FIELDS = ("patch_w", "patch_b", "text0_w", "text0_b", "text2_w", "text2_b", "time0_w", "time0_b",
+               "time2_w", "time2_b", "tproj_w", "tproj_b", "head_w", "head_b", "modulation",
+               "head_modulation", "rope_cs")
+
+
+class _Weights(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in _TOP_FIELDS] + [("layers", ctypes.POINTER(_LayerW))]
+
+
+class _Step(ctypes.Structure):
+    _fields_ = [("x", c_vp), ("t", c_vp), ("context", c_vp), ("out", c_vp),
+                ("F", ctypes.c_int), ("gh", ctypes.c_int), ("gw", ctypes.c_int),
+                ("kv_k", ctypes.POINTER(c_vp)), ("kv_v", ctypes.POINTER(c_vp)), ("kv_row_stride", ctypes.c_int64),
+                ("ca_k", ctypes.POINTER(c_vp)), ("ca_v", ctypes.POINTER(c_vp)),
+                ("compute_cross_kv", ctypes.c_int), ("cache_row0", ctypes.c_int),
+                ("kv_lo", ctypes.c_int), ("kv_hi", ctypes.c_int), ("start_frame", ctypes.c_int),
+                ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int)]
+
+
+_lib.EXTRA_SIGNATURES["rtv_dit_forward"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step),
+                                            c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_silu"] = [c_vp, c_vp, ctypes.c_int64, c_vp]
+
+
+class BlockCausalMask:
+    """Stands in for the flex-attention BlockMask the reference builds in get_block_mask
+    (causal_model.py:108-141): the rule `kv_idx < ends[q_idx]` with blocks of
+    num_frame_per_block * frame_seqlen tokens is a per-query key-prefix length, which the attention
+    kernel evaluates arithmetically — no mask tensor exists."""
+
+    def __init__(self, num_frames, frame_seqlen, num_frame_per_block, local_attn_size=-1):
+        if local_attn_size != -1:
+            raise NotImplementedError("local-window block masks are not used by the inference path")
+        self.num_frames, self.frame_seqlen = num_frames, frame_seqlen
+        self.num_frame_per_block = num_frame_per_block
+        self.block_tokens = frame_seqlen * num_frame_per_block
+
+    def __repr__(self):
+        return f"BlockCausalMask(frames={self.num_frames}, block_tokens={self.block_tokens})"
+
+
+class _SelfAttnHandle:
+    """blocks[i].self_attn attribute surface (causal_model.py:174-216)."""
+
+    def __init__(self, local_attn_size, sink_size):
+        self.local_attn_size = local_attn_size
+        self.sink_size = sink_size
+        self.num_frame_per_block = 1
+        self.fused_projections = True  # q/k/v are always stored fused here
+
+    @property
+    def max_attention_size(self):
+        return 32760 if self.local_attn_size == -1 else self.local_attn_size * 1560
+
+    def fuse_projections(self):
+        self.fused_projections = True
+
+
+class CausalWanModel:
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, local_attn_size=-1,
+                 sink_size=0, qk_norm=True, cross_attn_norm=True, eps=1e-6, device="cuda"):
+        if model_type != "t2v" or tuple(patch_size) != (1, 2, 2) or not qk_norm or not cross_attn_norm:
+            raise NotImplementedError("the MI355X hot path implements the t2v causal model (patch 1x2x2, qk_norm, cross_attn_norm)")
+        if dim % num_heads or dim // num_heads != 128:
+            raise ValueError("head_dim must be 128")
+        self.model_type, self.patch_size = model_type, tuple(patch_size)
+        self.text_len, self.in_dim, self.dim, self.ffn_dim = text_len, in_dim, dim, ffn_dim
+        self.freq_dim, self.text_dim, self.out_dim = freq_dim, text_dim, out_dim
+        self.num_heads, self.num_layers, self.eps = num_heads, num_layers, eps
+        self.local_attn_size, self.sink_size = local_attn_size, sink_size
+        self.device = torch.device(device)
+        self.config = types.SimpleNamespace(num_heads=num_heads, dim=dim, num_layers=num_layers, ffn_dim=ffn_dim)
+        self.blocks = [types.SimpleNamespace(self_attn=_SelfAttnHandle(local_attn_size, sink_size))
+                       for _ in range(num_layers)]
+        self.block_mask = None
+        self.num_frame_per_block = 1
+        self.independent_first_frame = False
+        self.gemm_tile_cfg = 0
+        self._tensors = {}      # name -> device tensor (keeps the memory alive)
+        self._w = None          # ctypes weight table
+        self._ws = {}           # (F, gh, gw) -> workspace tensor
+        self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps)
+
+    # ------------------------------------------------------------------ nn.Module-ish conveniences
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def parameters(self):
+        return iter(self._tensors.values())
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict=True):
+        """Accepts the reference's state_dict names (causal_model.py module tree).  q/k/v are fused into
+        to_qkv here (what `fuse_projections`, causal_model.py:203-216, does at load time in
+        release_server.py:176-177); an already-fused `to_qkv` entry is accepted as well."""
+        dev, bf = self.device, torch.bfloat16
+        t = {}
+
+        def get(name):
+            if name not in sd:
+                raise KeyError(f"missing weight {name}")
+            return sd[name].detach().to(device=dev, dtype=bf).contiguous()
+
+        t["patch_w"] = get("patch_embedding.weight").reshape(self.dim, -1).contiguous()
+        t["patch_b"] = get("patch_embedding.bias")
+        for dst, src in (("text0", "text_embedding.0"), ("text2", "text_embedding.2"), ("time0", "time_embedding.0"),
+                         ("time2", "time_embedding.2"), ("tproj", "time_projection.1"), ("head", "head.head")):
+            t[dst + "_w"], t[dst + "_b"] = get(src + ".weight"), get(src + ".bias")
+        t["head_modulation"] = get("head.modulation").reshape(2, self.dim).contiguous()
+        t["modulation"] = torch.stack([get(f"blocks.{i}.modulation").reshape(6, self.dim)
+                                       for i in range(self.num_layers)]).contiguous()
+        t["rope_cs"] = rope_cos_sin_table(self.dim // self.num_heads).to(dev)
+        layers = (_LayerW * self.num_layers)()
+        for i in range(self.num_layers):
+            p, sa, ca = f"blocks.{i}", f"blocks.{i}.self_attn", f"blocks.{i}.cross_attn"
+            lt = {}
+            if sa + ".to_qkv.weight" in sd:
+                lt["qkv_w"], lt["qkv_b"] = get(sa + ".to_qkv.weight"), get(sa + ".to_qkv.bias")
+            else:
+                lt["qkv_w"] = torch.cat([get(sa + ".q.weight"), get(sa + ".k.weight"), get(sa + ".v.weight")]).contiguous()
+                lt["qkv_b"] = torch.cat([get(sa + ".q.bias"), get(sa + ".k.bias"), get(sa + ".v.bias")]).contiguous()
+            lt["norm_q_w"], lt["norm_k_w"] = get(sa + ".norm_q.weight"), get(sa + ".norm_k.weight")
+            lt["o_w"], lt["o_b"] = get(sa + ".o.weight"), get(sa + ".o.bias")
+            lt["norm3_w"], lt["norm3_b"] = get(p + ".norm3.weight"), get(p + ".norm3.bias")
+            for m in ("q", "k", "v", "o"):
+                lt[f"c{m}_w"], lt[f"c{m}_b"] = get(f"{ca}.{m}.weight"), get(f"{ca}.{m}.bias")
+            lt["cnorm_q_w"], lt["cnorm_k_w"] = get(ca + ".norm_q.weight"), get(ca + ".norm_k.weight")
+            lt["ffn0_w"], lt["ffn0_b"] = get(p + ".ffn.0.weight"), get(p + ".ffn.0.bias")
+            lt["ffn2_w"], lt["ffn2_b"] = get(p + ".ffn.2.weight"), get(p + ".ffn.2.bias")
+            for name in _LAYER_FIELDS:
+                setattr(layers[i], name, lt[name].data_ptr())
+                t[f"L{i}.{name}"] = lt[name]
+        w = _Weights()
+        for name in _TOP_FIELDS:
+            setattr(w, name, t[name].data_ptr())
+        w.layers = ctypes.cast(layers, ctypes.POINTER(_LayerW))
+        self._layers_arr = layers
+        self._tensors, self._w = t, w
+        return [], []
+
+    def init_random_weights(self, seed=0, std=0.02):
+        """Synthetic weights of the right architecture generated directly on the GPU (bench.py: there is no
+        checkpoint offline).  Scales follow init_weights (causal_model.py:1151-1173) with a non-zero head."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        d, ffn, bf = self.dim, self.ffn_dim, torch.bfloat16
+
+        def rnd(*shape, s=std):
+            return (torch.randn(*shape, generator=g, device=self.device, dtype=torch.float32) * s).to(bf)
+
+        def xav(o, i):
+            return rnd(o, i, s=(2.0 / (i + o)) ** 0.5)
+
+        sd = {"patch_embedding.weight": xav(d, self.in_dim * 4).view(d, self.in_dim, 1, 2, 2), "patch_embedding.bias": rnd(d),
+              "text_embedding.0.weight": rnd(d, self.text_dim), "text_embedding.0.bias": rnd(d),
+              "text_embedding.2.weight": rnd(d, d), "text_embedding.2.bias": rnd(d),
+              "time_embedding.0.weight": rnd(d, self.freq_dim), "time_embedding.0.bias": rnd(d),
+              "time_embedding.2.weight": rnd(d, d), "time_embedding.2.bias": rnd(d),
+              "time_projection.1.weight": xav(6 * d, d), "time_projection.1.bias": rnd(6 * d),
+              "head.head.weight": rnd(self.out_dim * 4, d), "head.head.bias": rnd(self.out_dim * 4),
+              "head.modulation": rnd(1, 2, d, s=d ** -0.5)}
+        for i in range(self.num_layers):
+            p = f"blocks.{i}"
+            sd[f"{p}.self_attn.to_qkv.weight"], sd[f"{p}.self_attn.to_qkv.bias"] = xav(3 * d, d), rnd(3 * d)
+            sd[f"{p}.self_attn.o.weight"], sd[f"{p}.self_attn.o.bias"] = xav(d, d), rnd(d)
+            for a in ("self_attn", "cross_attn"):
+                sd[f"{p}.{a}.norm_q.weight"] = 1 + rnd(d, s=0.1)
+                sd[f"{p}.{a}.norm_k.weight"] = 1 + rnd(d, s=0.1)
+            for m in ("q", "k", "v", "o"):
+                sd[f"{p}.cross_attn.{m}.weight"], sd[f"{p}.cross_attn.{m}.bias"] = xav(d, d), rnd(d)
+            sd[f"{p}.norm3.weight"], sd[f"{p}.norm3.bias"] = 1 + rnd(d, s=0.1), rnd(d, s=0.05)
+            sd[f"{p}.ffn.0.weight"], sd[f"{p}.ffn.0.bias"] = xav(ffn, d), rnd(ffn)
+            sd[f"{p}.ffn.2.weight"], sd[f"{p}.ffn.2.bias"] = xav(d, ffn), rnd(d)
+            sd[f"{p}.modulation"] = rnd(1, 6, d, s=d ** -0.5)
+        self.load_state_dict(sd)
+        return self
+
+    # ------------------------------------------------------------------ mask builder (API parity)
+    @staticmethod
+    def _prepare_blockwise_causal_attn_mask(device=None, num_frames=21, frame_seqlen=1560, num_frame_per_block=1,
+                                            local_attn_size=-1):
+        return BlockCausalMask(num_frames, frame_seqlen, num_frame_per_block, local_attn_size)
+
+    # ------------------------------------------------------------------ forward
+    def _workspace(self, F, gh, gw):
+        key = (F, gh, gw)
+        ws = self._ws.get(key)
+        if ws is None:
+            lib = _lib.load()
+            lib.rtv_dit_workspace_bytes.restype = ctypes.c_size_t
+            lib.rtv_dit_workspace_bytes.argtypes = [ctypes.POINTER(_Cfg), ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            n = lib.rtv_dit_workspace_bytes(ctypes.byref(self._cfg), F, gh, gw)
+            ws = torch.empty(n + 256, dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _cache_window(self, kv_cache, num_new, current_start, frame_seqlen):
+        """Integer bookkeeping of CausalWanSelfAttention.forward (causal_model.py:305-314 and :349-392).
+        Returns (cache_row0, kv_lo, kv_hi, start_frame, causal_block) and updates every layer's indices;
+        performs the rolling eviction copy when the local window overflows (:363-379)."""
+        c0 = kv_cache[0]
+        if self.block_mask is not None:  # KV-recompute pass over clean context frames
+            local_end = num_new
+            for c in kv_cache:
+                c["global_end_index"] = local_end
+                c["local_end_index"] = local_end
+            return 0, 0, local_end, 0, self.block_mask.block_tokens
+        sa = self.blocks[0].self_attn
+        g_end, l_end = int(c0["global_end_index"]), int(c0["local_end_index"])
+        current_end = current_start + num_new
+        kv_size = c0["k"].shape[1]
+        sink_tokens = sa.sink_size * frame_seqlen
+        if sa.local_attn_size != -1 and current_end > g_end and num_new + l_end > kv_size:
+            evicted = num_new + l_end - kv_size
+            rolled = l_end - evicted - sink_tokens
+            for c in kv_cache:  # K8: eviction as a shift copy, like the reference (ring indexing is future work)
+                for n in ("k", "v"):
+                    c[n][:, sink_tokens:sink_tokens + rolled] = \
+                        c[n][:, sink_tokens + evicted:sink_tokens + evicted + rolled].clone()
+            local_end = l_end + current_end - g_end - evicted
+        else:
+            local_end = l_end + current_end - g_end
+        local_start = local_end - num_new
+        if local_start < 0 or local_end > kv_size:
+            raise RuntimeError(f"KV cache window [{local_start}, {local_end}) outside cache of {kv_size} rows")
+        lo = max(0, local_end - sa.max_attention_size)
+        for c in kv_cache:
+            c["global_end_index"] = current_end
+            c["local_end_index"] = local_end
+        return local_start, lo, local_end, current_start // frame_seqlen, 0
+
+    def _forward_inference(self, x, t, context, seq_len=None, clip_fea=None, y=None, kv_cache=None,
+                           crossattn_cache=None, current_start=0, cache_start=0):
+        if self._w is None:
+            raise RuntimeError("weights not loaded")
+        if kv_cache is None or crossattn_cache is None:
+            raise NotImplementedError("the hot path is the KV-cached inference forward (causal_model.py:825-954)")
+        if clip_fea is not None or y is not None:
+            raise NotImplementedError("i2v conditioning is out of scope")
+        xs = list(x) if not torch.is_tensor(x) else [x[i] for i in range(x.shape[0])]
+        B = len(xs)
+        if B != 1:
+            raise NotImplementedError("batch size 1 (the streaming server path); run sessions as replicas")
+        u = xs[0]
+        if not u.is_cuda:
+            raise RuntimeError("realtime_video_amd.CausalWanModel needs GPU tensors (no CPU fallback)")
+        C, F, Hh, Ww = u.shape
+        gh, gw = Hh // 2, Ww // 2
+        fs = gh * gw
+        M = F * fs
+        if seq_len is not None and M > seq_len:
+            raise AssertionError("sequence longer than seq_len")
+        u = u.to(torch.bfloat16).contiguous()
+        tt = t.reshape(-1).to(device=u.device, dtype=torch.float32).contiguous()
+        if tt.numel() != F:
+            raise ValueError("t must hold one timestep per latent frame")
+        need_cross = not all(bool(c["is_init"]) for c in crossattn_cache)
+        ctx = None
+        if need_cross:
+            cu = context[0] if not torch.is_tensor(context) else context[0]
+            ctx = torch.zeros(self.text_len, self.text_dim, dtype=torch.bfloat16, device=u.device)
+            ctx[:cu.shape[0]] = cu.to(torch.bfloat16)
+        row0, lo, hi, start_frame, causal_block = self._cache_window(kv_cache, M, current_start, fs)
+        L = self.num_layers
+        for c in kv_cache:
+            if c["k"].stride(1) != c["k"].stride(2) * c["k"].shape[2] or c["k"].stride(3) != 1:
+                raise ValueError("KV cache tensors must be [B, kv_size, H, 128] with dense [H, 128]")
+        def ptr_array(tensors):
+            arr = (c_vp * L)(*[t_.data_ptr() for t_ in tensors])
+            return arr, ctypes.cast(arr, ctypes.POINTER(c_vp))
+
+        kk_keep, kk = ptr_array([c["k"] for c in kv_cache])
+        kv_keep, kv = ptr_array([c["v"] for c in kv_cache])
+        ck_keep, ck = ptr_array([c["k"] for c in crossattn_cache])
+        cv_keep, cv = ptr_array([c["v"] for c in crossattn_cache])
+        out = torch.empty((self.out_dim, F, Hh, Ww), dtype=torch.bfloat16, device=u.device)
+        ws = self._workspace(F, gh, gw)
+        ws_ptr = (ws.data_ptr() + 255) & ~255
+        st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
+                   F, gh, gw, kk, kv, kv_cache[0]["k"].stride(1), ck, cv, int(need_cross), row0, lo, hi,
+                   start_frame, causal_block, int(self.gemm_tile_cfg))
+        _lib.call("rtv_dit_forward", ctypes.byref(self._cfg), ctypes.byref(self._w), ctypes.byref(st),
+                  c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())),
+                  c_vp(torch.cuda.current_stream().cuda_stream))
+        if need_cross:
+            for c in crossattn_cache:
+                c["is_init"] = True
+        return out.unsqueeze(0)
+
+    def forward(self, *args, **kwargs):
+        return self._forward_inference(*args, **kwargs)
+
+    __call__ = forward

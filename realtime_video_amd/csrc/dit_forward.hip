@@ -1,0 +1,171 @@
+// Whole-forward orchestrator: one call = CausalWanModel._forward_inference
+// (wan/modules/causal_model.py:825-954; block body :440-492; head :495-523; unpatchify :1126-1149).
+// Pure launch sequencing over the kernels of this library on ONE stream: no allocation, no sync, so
+// the call is hipGraph-capturable.  13 launches per DiT layer.
+#include "rtv_common.h"
+#include "rtv_internal.h"
+
+namespace rtv {
+
+__global__ void silu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = f32_to_bf16(silu(bf16_to_f32(x[i])));
+}
+
+struct Workspace {
+  char* base;
+  size_t off, cap;
+  bool ok;
+  void* take(size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    if (base && a + bytes > cap) ok = false;
+    off = a + bytes;
+    return base ? base + a : nullptr;
+  }
+};
+
+struct DitBuffers {
+  uint16_t *x, *xn, *qkv, *q, *ao, *h, *prow, *hrow;
+  uint16_t *sinus, *te1, *e, *se, *e0, *emod, *ehead, *ctx1, *ctx, *ktmp;
+};
+
+static size_t carve(const rtv_dit_config* c, int F, int gh, int gw, char* base, size_t cap, DitBuffers* b,
+                    bool* ok) {
+  Workspace ws{base, 0, cap, true};
+  const size_t M = (size_t)F * gh * gw, d = c->dim, e = 2;
+  DitBuffers t;
+  t.x = (uint16_t*)ws.take(M * d * e);
+  t.xn = (uint16_t*)ws.take(M * d * e);
+  t.qkv = (uint16_t*)ws.take(M * 3 * d * e);
+  t.q = (uint16_t*)ws.take(M * d * e);
+  t.ao = (uint16_t*)ws.take(M * d * e);
+  t.h = (uint16_t*)ws.take(M * (size_t)c->ffn_dim * e);
+  t.prow = (uint16_t*)ws.take(M * (size_t)c->in_dim * 4 * e);
+  t.hrow = (uint16_t*)ws.take(M * (size_t)c->out_dim * 4 * e);
+  t.sinus = (uint16_t*)ws.take((size_t)F * c->freq_dim * e);
+  t.te1 = (uint16_t*)ws.take((size_t)F * d * e);
+  t.e = (uint16_t*)ws.take((size_t)F * d * e);
+  t.se = (uint16_t*)ws.take((size_t)F * d * e);
+  t.e0 = (uint16_t*)ws.take((size_t)F * 6 * d * e);
+  t.emod = (uint16_t*)ws.take((size_t)c->num_layers * F * 6 * d * e);
+  t.ehead = (uint16_t*)ws.take((size_t)F * 2 * d * e);
+  t.ctx1 = (uint16_t*)ws.take((size_t)c->text_len * d * e);
+  t.ctx = (uint16_t*)ws.take((size_t)c->text_len * d * e);
+  t.ktmp = (uint16_t*)ws.take((size_t)c->text_len * d * e);
+  if (b) *b = t;
+  if (ok) *ok = ws.ok;
+  return ws.off;
+}
+
+}  // namespace rtv
+
+using namespace rtv;
+
+#define RTV_TRY(expr)        \
+  do {                       \
+    int _s = (expr);         \
+    if (_s != 0) return _s;  \
+  } while (0)
+
+extern "C" int rtv_silu(const void* x, void* out, int64_t n, rtv_stream_t stream) {
+  if (n <= 0) return 0;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(silu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)out, n);
+  return check_launch("silu");
+}
+
+extern "C" size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw) {
+  if (!cfg || F <= 0 || gh <= 0 || gw <= 0) return 0;
+  return carve(cfg, F, gh, gw, nullptr, 0, nullptr, nullptr) + 256;
+}
+
+static int linear(const void* a, int K, const void* w, const void* bias, void* out, int M, int N, int act,
+                  const void* gate, int gate_stride, int rpf, const void* res, int cfg, rtv_stream_t s) {
+  return rtv_gemm(a, K, w, K, out, N, M, N, K, bias, act, gate, gate_stride, rpf, res, N, RTV_DTYPE_BF16, cfg, s);
+}
+
+extern "C" int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st,
+                               void* workspace, size_t workspace_bytes, rtv_stream_t stream) {
+  if (!cfg || !w || !st || !workspace) return set_error(-1, "dit_forward: null argument");
+  const int d = cfg->dim, H = cfg->num_heads, L = cfg->num_layers, ffn = cfg->ffn_dim;
+  if (H <= 0 || d % H || d / H != 128) return set_error(-1, "dit_forward: head_dim must be 128");
+  const int F = st->F, gh = st->gh, gw = st->gw;
+  const int fs = gh * gw, M = F * fs;
+  if (M <= 0) return set_error(-1, "dit_forward: empty token grid");
+  if (st->kv_lo < 0 || st->kv_hi <= st->kv_lo) return set_error(-1, "dit_forward: empty attention window");
+  if (st->cache_row0 < 0 || st->cache_row0 + M > st->kv_hi)
+    return set_error(-1, "dit_forward: the rows written by this call must lie inside the attention window");
+  if (((uintptr_t)workspace) & 255) return set_error(-1, "dit_forward: workspace must be 256-byte aligned");
+  DitBuffers b;
+  bool ok = true;
+  carve(cfg, F, gh, gw, (char*)workspace, workspace_bytes, &b, &ok);
+  if (!ok) return set_error(-1, "dit_forward: workspace too small (see rtv_dit_workspace_bytes)");
+  const int tc = st->gemm_tile_cfg;
+  const int hd = d / H;
+
+  // ---- embeddings (causal_model.py:874-902)
+  RTV_TRY(rtv_patchify(st->x, b.prow, cfg->in_dim, F, gh, gw, stream));
+  RTV_TRY(linear(b.prow, cfg->in_dim * 4, w->patch_w, w->patch_b, b.x, M, d, 0, nullptr, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_sinusoidal_embedding(st->t, b.sinus, F, cfg->freq_dim, stream));
+  RTV_TRY(linear(b.sinus, cfg->freq_dim, w->time0_w, w->time0_b, b.te1, F, d, RTV_ACT_SILU, nullptr, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(b.te1, d, w->time2_w, w->time2_b, b.e, F, d, 0, nullptr, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_silu(b.e, b.se, (int64_t)F * d, stream));
+  RTV_TRY(linear(b.se, d, w->tproj_w, w->tproj_b, b.e0, F, 6 * d, 0, nullptr, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_modulation_table(w->modulation, b.e0, b.emod, L, F, 6, 6, d, stream));
+  RTV_TRY(rtv_modulation_table(w->head_modulation, b.e, b.ehead, 1, F, 2, 1, d, stream));
+
+  // ---- text context -> cross-attention K/V caches, only while they are not initialised
+  //      (model.py:186-192; the text MLP output is consumed nowhere else, causal_model.py:897-902)
+  if (st->compute_cross_kv) {
+    if (!st->context) return set_error(-1, "dit_forward: context required to initialise the cross-attention cache");
+    const int T = cfg->text_len;
+    RTV_TRY(linear(st->context, cfg->text_dim, w->text0_w, w->text0_b, b.ctx1, T, d, RTV_ACT_GELU_TANH, nullptr, 0, 0, nullptr, tc, stream));
+    RTV_TRY(linear(b.ctx1, d, w->text2_w, w->text2_b, b.ctx, T, d, 0, nullptr, 0, 0, nullptr, tc, stream));
+    for (int l = 0; l < L; ++l) {
+      const rtv_dit_layer_weights& lw = w->layers[l];
+      RTV_TRY(linear(b.ctx, d, lw.ck_w, lw.ck_b, b.ktmp, T, d, 0, nullptr, 0, 0, nullptr, tc, stream));
+      RTV_TRY(rtv_rmsnorm(b.ktmp, d, st->ca_k[l], d, T, d, cfg->eps, lw.cnorm_k_w, stream));
+      RTV_TRY(linear(b.ctx, d, lw.cv_w, lw.cv_b, st->ca_v[l], T, d, 0, nullptr, 0, 0, nullptr, tc, stream));
+    }
+  }
+
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int64_t rs = st->kv_row_stride;
+  const int Lkv = st->kv_hi - st->kv_lo;
+  const int q_offset = st->cache_row0 - st->kv_lo;  // position of query row 0 inside the window
+
+  for (int l = 0; l < L; ++l) {
+    const rtv_dit_layer_weights& lw = w->layers[l];
+    const uint16_t* em = b.emod + (size_t)l * F * 6 * d;  // [F][6][d]: shift_sa, scale_sa, gate_sa, shift_ffn, scale_ffn, gate_ffn
+    uint16_t* kc = (uint16_t*)st->kv_k[l];
+    uint16_t* vc = (uint16_t*)st->kv_v[l];
+    // -- self attention (causal_model.py:470-476)
+    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, em + 0 * d, em + 1 * d, 6 * d, fs, nullptr, nullptr, stream));
+    RTV_TRY(linear(b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, M, 3 * d, 0, nullptr, 0, 0, nullptr, tc, stream));
+    RTV_TRY(rtv_qk_norm_rope_cache(b.qkv, b.q, kc, vc, rs, st->cache_row0, M, d, H, cfg->eps, lw.norm_q_w,
+                                   lw.norm_k_w, w->rope_cs, F, gh, gw, st->start_frame, stream));
+    RTV_TRY(rtv_attn_fwd(b.q, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, b.ao, 1, M, Lkv, H, hd,
+                         0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block, st->causal_block > 0 ? q_offset : 0,
+                         RTV_DTYPE_BF16, stream));
+    RTV_TRY(linear(b.ao, d, lw.o_w, lw.o_b, b.x, M, d, 0, em + 2 * d, 6 * d, fs, b.x, tc, stream));
+    // -- cross attention (causal_model.py:480, model.py:171-228)
+    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, nullptr, nullptr, 0, 0, lw.norm3_w, lw.norm3_b, stream));
+    RTV_TRY(linear(b.xn, d, lw.cq_w, lw.cq_b, b.qkv, M, d, 0, nullptr, 0, 0, nullptr, tc, stream));
+    RTV_TRY(rtv_rmsnorm(b.qkv, d, b.q, d, M, d, cfg->eps, lw.cnorm_q_w, stream));
+    RTV_TRY(rtv_attn_fwd(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, M, cfg->text_len, H, hd, 0, d, 0, d, 0, d, 0, d,
+                         scale, 0, 0, RTV_DTYPE_BF16, stream));
+    RTV_TRY(linear(b.ao, d, lw.co_w, lw.co_b, b.x, M, d, 0, nullptr, 0, 0, b.x, tc, stream));
+    // -- FFN (causal_model.py:482-488)
+    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, em + 3 * d, em + 4 * d, 6 * d, fs, nullptr, nullptr, stream));
+    RTV_TRY(linear(b.xn, d, lw.ffn0_w, lw.ffn0_b, b.h, M, ffn, RTV_ACT_GELU_TANH, nullptr, 0, 0, nullptr, tc, stream));
+    RTV_TRY(linear(b.h, ffn, lw.ffn2_w, lw.ffn2_b, b.x, M, d, 0, em + 5 * d, 6 * d, fs, b.x, tc, stream));
+  }
+
+  // ---- head + unpatchify (causal_model.py:512-523, :1126-1149)
+  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, b.ehead + 0 * d, b.ehead + 1 * d, 2 * d, fs, nullptr, nullptr, stream));
+  RTV_TRY(linear(b.xn, d, w->head_w, w->head_b, b.hrow, M, cfg->out_dim * 4, 0, nullptr, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_unpatchify(b.hrow, st->out, cfg->out_dim, F, gh, gw, stream));
+  return 0;
+}

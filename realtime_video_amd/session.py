@@ -1,0 +1,190 @@
+"""Mirror of the reference's streaming block loop: `GenerationSession` (release_server.py:344-751)
+restricted to the text-to-video hot path — `init_models` (:542-560), `get_clean_context_frames`
+(:563-576), `recompute_kv_cache` (:588-633), `generate_block_internal` (:636-736).  Host
+orchestration stays Python on PyTorch-ROCm exactly as in the reference; every forward it issues is the
+native `rtv_dit_forward` / VAE kernel path.  The web layer, webcam / v2v input side and prompt
+interpolation are outside the hot-path scope.
+"""
+import types
+from collections import deque
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from .scheduler import FlowMatchScheduler, get_denoising_schedule
+
+
+@dataclass
+class GenerateParams:
+    """Fields of the reference's pydantic GenerateParams (release_server.py:315-341) used by T2V."""
+    prompt: str = ""
+    width: int = 832
+    height: int = 480
+    seed: Optional[int] = None
+    strength: float = 1.0
+    context_noise: float = 0.0
+    keep_first_frame: bool = False
+    kv_cache_num_frames: int = 3
+    num_blocks: int = 9
+    num_denoising_steps: Optional[int] = 5  # "use 4 for performance"
+    timestep_shift: float = 5.0
+
+
+def Models(transformer, pipeline, text_encoder=None, vae_decoder=None, vae_encoder=None):
+    return types.SimpleNamespace(transformer=transformer, pipeline=pipeline, text_encoder=text_encoder,
+                                 vae_decoder=vae_decoder, vae_encoder=vae_encoder)
+
+
+class StaticTextEncoder:
+    """Counterpart of release_server.py:125-133: returns a fixed conditioning dict (used with synthetic
+    prompt embeddings — the UMT5 encoder runs once per prompt and is outside the hot path)."""
+
+    def __init__(self, prompt_embeds):
+        self.cond = {"prompt_embeds": prompt_embeds}
+
+    def __call__(self, text_prompts=None):
+        return dict(self.cond)
+
+
+class GenerationSession:
+    def __init__(self, params: GenerateParams, models, frame_callback: Optional[Callable] = None, device="cuda"):
+        self.params, self.models = params, models
+        self.frame_callback = frame_callback or (lambda *a, **k: None)
+        self.gpu = torch.device(device)
+        self.block_idx = 0
+        self.width, self.height = params.width // 8 * 8, params.height // 8 * 8
+        self.latent_width, self.latent_height = self.width // 8, self.height // 8
+        self.kv_cache_num_frames = params.kv_cache_num_frames
+        self.num_blocks = params.num_blocks
+        self.frame_context_cache = deque(maxlen=1 + (params.kv_cache_num_frames - 1) * 4)
+        self.decode_vae_cache = [None] * 55
+        self.num_frame_per_block = 3
+        self.rnd = torch.Generator(self.gpu).manual_seed(params.seed if params.seed is not None else 0)
+        shape = [1, self.num_blocks * self.num_frame_per_block, 16, self.latent_height, self.latent_width]
+        self.all_latents = torch.zeros(shape, device=self.gpu, dtype=torch.bfloat16)
+        self.noise = torch.randn(shape, device=self.gpu, dtype=torch.bfloat16, generator=self.rnd)
+        self.current_start_frame = 0
+        self.total_frames_sent = 0
+        self.current_prompt_embeds = None
+        self.resume_latents = None
+        self.last_pred = None
+        self.init_models(models, params)
+        self.denoising_step_list = get_denoising_schedule(self.zero_padded_timesteps, params.strength,
+                                                          steps=params.num_denoising_steps)
+
+    def _randn(self, shape):
+        """Re-noising draw of release_server.py:692 (bf16 from the session generator); a hook so tests can
+        feed the same stream to the CPU oracle."""
+        return torch.randn(*shape, generator=self.rnd, device=self.gpu, dtype=torch.bfloat16)
+
+    # release_server.py:542-560
+    def init_models(self, models, params):
+        pipe = models.pipeline
+        attn_size = params.kv_cache_num_frames + pipe.num_frame_per_block
+        for block in pipe.generator.model.blocks:
+            block.self_attn.local_attn_size = -1
+        pipe.local_attn_size = attn_size
+        pipe._initialize_kv_cache(batch_size=1, dtype=torch.bfloat16, device=self.gpu)
+        pipe._initialize_crossattn_cache(batch_size=1, dtype=torch.bfloat16, device=self.gpu)
+        pipe.generator.model.block_mask = None
+        pipe.scheduler = FlowMatchScheduler(shift=params.timestep_shift, sigma_min=0.0, extra_one_step=True)
+        pipe.scheduler.set_timesteps(1000, training=True)
+        st = pipe.scheduler.timesteps
+        self.zero_padded_timesteps = torch.cat((st.cpu(), torch.tensor([0], dtype=torch.float32))).to(self.gpu)
+        pipe.scheduler.to(self.gpu)
+
+    # release_server.py:563-576
+    def get_clean_context_frames(self, models):
+        c = self.kv_cache_num_frames
+        ctx = self.all_latents[:, :self.current_start_frame]
+        if self.params.keep_first_frame or (self.block_idx - 1) * models.pipeline.num_frame_per_block < c:
+            if c == 1:
+                return ctx[:, :1]
+            return torch.cat((ctx[:, :1], ctx[:, 1:][:, -c + 1:]), dim=1)
+        tail = ctx[:, 1:][:, -c + 1:]
+        if models.vae_encoder is None:
+            raise RuntimeError("first-frame re-encode needs a VAE encoder (release_server.py:572-575); "
+                               "set keep_first_frame=True to run without one")
+        first = models.vae_encoder(self.frame_context_cache[0][0].half())  # -> [1, 1, 16, h, w]
+        return torch.cat((first.to(tail), tail), dim=1)
+
+    # release_server.py:588-633
+    def recompute_kv_cache(self, models):
+        pipe = models.pipeline
+        if self.block_idx == 0:
+            pipe._initialize_kv_cache(batch_size=1, dtype=torch.bfloat16, device=self.gpu)
+            if self.resume_latents is not None:
+                self.current_start_frame = self.resume_latents.shape[1]
+                self.all_latents[:, :self.current_start_frame] = self.resume_latents
+            else:
+                return self.current_start_frame
+        for block in pipe.generator.model.blocks:
+            block.self_attn.num_frame_per_block = pipe.num_frame_per_block
+        start = min(self.current_start_frame, self.params.kv_cache_num_frames)
+        ctx = self.get_clean_context_frames(models)
+        pipe._initialize_kv_cache(batch_size=ctx.shape[0], dtype=ctx.dtype, device=ctx.device)
+        model = pipe.generator.model
+        model.block_mask = model._prepare_blockwise_causal_attn_mask(
+            device=str(ctx.device), num_frames=ctx.shape[1], frame_seqlen=pipe.frame_seq_length,
+            num_frame_per_block=pipe.num_frame_per_block, local_attn_size=-1)
+        t0 = torch.zeros([ctx.shape[0], ctx.shape[1]], device=ctx.device, dtype=torch.int64)
+        models.transformer(noisy_image_or_video=ctx, conditional_dict=self.conditional_dict, timestep=t0,
+                           kv_cache=pipe.kv_cache1, crossattn_cache=pipe.crossattn_cache,
+                           current_start=start * pipe.frame_seq_length)
+        model.block_mask = None
+        return start
+
+    # release_server.py:636-736
+    @torch.inference_mode()
+    def generate_block_internal(self, models):
+        idx = self.block_idx
+        if idx >= self.num_blocks:
+            return None
+        pipe = models.pipeline
+        nfpb = pipe.num_frame_per_block
+        if self.current_prompt_embeds is None:
+            self.conditional_dict = models.text_encoder(text_prompts=[self.params.prompt])
+            for k, v in self.conditional_dict.items():
+                self.conditional_dict[k] = v.to(dtype=torch.bfloat16).contiguous()
+            self.current_prompt_embeds = self.conditional_dict["prompt_embeds"]
+        start = self.recompute_kv_cache(models)
+        noisy_input = self.noise[:, self.current_start_frame:self.current_start_frame + nfpb]
+        steps = self.denoising_step_list
+        denoised_pred = None
+        for index, current_timestep in enumerate(steps):
+            timestep = torch.ones([1, nfpb], device=self.gpu, dtype=torch.int64) * current_timestep
+            _, denoised_pred = models.transformer(
+                noisy_image_or_video=noisy_input, conditional_dict=self.conditional_dict, timestep=timestep,
+                kv_cache=pipe.kv_cache1, crossattn_cache=pipe.crossattn_cache,
+                current_start=start * pipe.frame_seq_length)
+            if index < len(steps) - 1:
+                next_timestep = steps[index + 1]
+                flat = denoised_pred.flatten(0, 1)
+                noisy_input = pipe.scheduler.add_noise(
+                    flat, self._randn(flat.shape),
+                    next_timestep * torch.ones([nfpb], device=self.gpu, dtype=torch.long)
+                ).unflatten(0, denoised_pred.shape[:2])
+        self.all_latents[:, self.current_start_frame:self.current_start_frame + nfpb] = denoised_pred
+        self.last_pred = denoised_pred
+        pixels = None
+        if models.vae_decoder is not None:
+            pixels, self.decode_vae_cache = models.vae_decoder(denoised_pred.half(), *self.decode_vae_cache)
+            self.frame_context_cache.extend(pixels.split(1, dim=1))
+            if idx == 0:
+                pixels = pixels[:, 3:]  # the first block yields 9 frames, 3 are dropped (:722-723)
+            self.most_recent_frame = pixels[:, -1:].clone()
+            event = torch.cuda.Event()
+            event.record()
+            self.frame_callback(pixels, [], event)
+            self.total_frames_sent += pixels.shape[1]
+        self.current_start_frame += nfpb
+        self.block_idx += 1
+        self.resume_latents = None
+        return pixels if pixels is not None else denoised_pred
+
+    def generate_block(self, models=None):
+        out = self.generate_block_internal(models or self.models)
+        if out is None:
+            raise StopIteration("all blocks generated")
+        return out
