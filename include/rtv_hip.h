@@ -170,6 +170,49 @@ size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw)
 int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step,
                     void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 
+/* ---- K6/K7: streaming VAE decoder ---------------------------------------------------------------
+ * fp16, channels-last activations [T][H][W][C].
+ * rtv_conv_cl: implicit-GEMM convolution replacing CausalConv3d / Conv2d / time_conv of the decoder
+ *   (wan/modules/vae.py:17-36; demo_utils/vae_block3.py:19-29,:61-72).  `in` is the concat buffer
+ *   [cached slices | new slices] for temporal kernels (output frame t reads slices t..t+kt-1); spatial
+ *   zero padding kh/2; w is [Cout][kt*kh*kw][Cin]; ups=1 reads the input through a nearest 2x upsampling
+ *   (output H,W are the upsampled dims); n_split>0 scatters output channel halves to frames 2t, 2t+1.
+ *   Cin % 32 == 0, Cout % 8 == 0; `zeros` = >=16 zero bytes. */
+int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
+                void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                int ups, int n_split, const void* zeros, rtv_stream_t stream);
+/* RMS_norm over channels (+SiLU) on channels-last pixels (wan/modules/vae.py:39-54): C in {96,192,384}. */
+int rtv_rmsnorm_silu_cl(const void* x, void* out, const void* gamma, int C, int64_t npix, int apply_silu,
+                        rtv_stream_t stream);
+/* row softmax of the single-head mid-block attention (vae.py:241-245): p[r][:n] = softmax(s[r][:n]), zero pad to ldp */
+int rtv_softmax_rows(const void* s, int lds, void* p, int ldp, int rows, int n, rtv_stream_t stream);
+
+typedef struct rtv_vae_conv { const void* w; const void* b; } rtv_vae_conv;       /* fp16 [Cout][taps][Cin], [Cout] */
+typedef struct rtv_vae_res {                                                        /* ResidualBlock, vae.py:175-209 */
+  const void* gamma0; rtv_vae_conv conv_a; const void* gamma3; rtv_vae_conv conv_b; rtv_vae_conv shortcut; /* shortcut.w nullable */
+} rtv_vae_res;
+typedef struct rtv_vae_attn {                                                       /* AttentionBlock, vae.py:212-251 */
+  const void* gamma; const void *wq, *bq, *wk, *bk, *wv, *bv, *wproj, *bproj;      /* wq/bq pre-scaled by 1/sqrt(384) */
+} rtv_vae_attn;
+typedef struct rtv_vae_weights {
+  const void *conv2_w, *conv2_b, *mean, *std;   /* float32: [16][16], [16], [16], [16] (vae_block3.py:181-193) */
+  rtv_vae_conv conv1;                            /* Cin padded 16 -> 32 */
+  rtv_vae_res mid0, mid2, up[12];
+  rtv_vae_attn attn;
+  rtv_vae_conv time_conv[2], resample[3];
+  const void* head_gamma;
+  rtv_vae_conv head;                             /* Cout padded 3 -> 8 */
+} rtv_vae_weights;
+
+/* Caller-owned arena: 32 feature caches (the first two slices of each conv's concat buffer) + scratch.
+ * Zero it before the first call of a stream (`first` = 1: feat_cache slots are None, the first latent
+ * frame skips the temporal upsampling, vae_block3.py:51-53). */
+size_t rtv_vae_arena_bytes(int h, int w);
+int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, int* W);
+/* z: fp16 [T][16][h][w] latents; pixels: float32 [T'][3][8h][8w] in [-1,1], T' = 4T (4T-3 when first). */
+int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first,
+                   void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
+
 /* ---- hardware-layout probes (test support; see csrc/probe.hip) --------------------------------- */
 int rtv_probe_mfma(const void* A /*[32][16] bf16*/, const void* B /*[16][32] bf16*/, void* D /*[32][32] f32*/,
                    rtv_stream_t stream);

@@ -156,10 +156,43 @@ def golden_rolling(ref):
     print("dit_rolling.pt", out["indices"])
 
 
+def vae_inputs(seed=21, h=8, w=12):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(1, 3, 16, h, w, generator=g) for _ in range(3)]
+
+
+def golden_vae(ref):
+    """Streaming VAE decoder (demo_utils/vae_block3.py:177-230), fp32 on CPU, 8x12 latents -> 64x96 px:
+    block 0 yields 9 frames (first latent frame skips the temporal upsampling), later blocks 12."""
+    from oracle import vae_oracle as vo
+    w = vo.make_vae_weights(seed=0)
+    dec = ref.vae_block3.VAEDecoderWrapper().eval()
+    missing, unexpected = dec.load_state_dict(w, strict=False)
+    assert not unexpected and set(missing) <= {"mean", "std"}, (missing, unexpected)
+    zs = vae_inputs()
+    cache = [None] * 55
+    out = {"weights_checksum": float(sum(v.double().abs().sum() for v in w.values())), "pixels": [],
+           "cache_shapes": []}
+    with torch.inference_mode():
+        for z in zs:
+            px, cache = dec(z, *cache)
+            out["pixels"].append(px.clone())
+            out["cache_shapes"].append([None if c is None else tuple(c.shape) for c in cache])
+        out["cache_sample"] = [None if c is None else c[0, ::7, :, ::3, ::5].clone() for c in cache]
+    torch.save(out, os.path.join(OUT, "vae_decoder.pt"))
+    print("vae_decoder.pt", [tuple(p.shape) for p in out["pixels"]])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    golden_ops(ref)
-    golden_dit(ref)
-    golden_rolling(ref)
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae"]
+    if "ops" in which:
+        golden_ops(ref)
+    if "dit" in which:
+        golden_dit(ref)
+    if "rolling" in which:
+        golden_rolling(ref)
+    if "vae" in which:
+        golden_vae(ref)

@@ -1,0 +1,228 @@
+"""CPU ORACLE (test infrastructure only) — restatement of the reference's streaming causal-conv3d VAE
+decoder: `VAEDecoderWrapper` / `VAEDecoder3d` / `Resample` (demo_utils/vae_block3.py:8-114, :177-230,
+:334-443) over the building blocks of wan/modules/vae.py (`CausalConv3d` :17-36, `RMS_norm` :39-54,
+`Upsample` :57-63, `ResidualBlock` :175-209, `AttentionBlock` :212-251).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.  Pinned
+against the reference's own modules through oracle/make_golden.py -> tests/golden/vae_decoder.pt
+(the upstream repo has no tests for this path).  Weights: plain dict with the reference's
+state_dict names (`decoder.*`, `conv2.*`).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+        0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+       3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+DIMS = [384, 384, 384, 192, 96]  # vae_block3.py:354 with dim=96, dim_mult=[1,2,4,4]
+CACHE_T = 2
+
+
+def causal_conv3d(x, weight, bias, padding, cache_x=None, stride=1):
+    """CausalConv3d.forward, wan/modules/vae.py:27-36.  padding = (pt, ph, pw) as given to the ctor."""
+    pad = [padding[2], padding[2], padding[1], padding[1], 2 * padding[0], 0]
+    if cache_x is not None and pad[4] > 0:
+        x = torch.cat([cache_x, x], dim=2)
+        pad[4] -= cache_x.shape[2]
+    return F.conv3d(F.pad(x, pad), weight, bias, stride=stride)
+
+
+def rms_norm(x, gamma):
+    """RMS_norm.forward (channel_first), wan/modules/vae.py:51-54."""
+    return F.normalize(x, dim=1) * (x.shape[1] ** 0.5) * gamma
+
+
+def _cached_conv(x, w, name, feat_cache, feat_idx):
+    """The cache idiom of ResidualBlock.forward (vae.py:193-206) / VAEDecoder3d.forward
+    (vae_block3.py:406-413): new cache = last 2 time slices of the conv INPUT (prepending the old
+    cache's last slice when only one new slice exists)."""
+    idx = feat_idx[0]
+    cache_x = x[:, :, -CACHE_T:].clone()
+    if cache_x.shape[2] < 2 and feat_cache[idx] is not None:
+        cache_x = torch.cat([feat_cache[idx][:, :, -1:], cache_x], dim=2)
+    out = causal_conv3d(x, w[name + ".weight"], w[name + ".bias"], (1, 1, 1), feat_cache[idx])
+    feat_cache[idx] = cache_x
+    feat_idx[0] += 1
+    return out
+
+
+def residual_block(x, w, pre, feat_cache, feat_idx):
+    """ResidualBlock.forward, vae.py:191-209 (residual = RMS_norm, SiLU, conv, RMS_norm, SiLU, Dropout, conv)."""
+    if pre + ".shortcut.weight" in w:
+        h = causal_conv3d(x, w[pre + ".shortcut.weight"], w[pre + ".shortcut.bias"], (0, 0, 0))
+    else:
+        h = x
+    x = F.silu(rms_norm(x, w[pre + ".residual.0.gamma"]))
+    x = _cached_conv(x, w, pre + ".residual.2", feat_cache, feat_idx)
+    x = F.silu(rms_norm(x, w[pre + ".residual.3.gamma"]))
+    x = _cached_conv(x, w, pre + ".residual.6", feat_cache, feat_idx)
+    return x + h
+
+
+def attention_block(x, w, pre):
+    """AttentionBlock.forward, vae.py:229-251 (single head over h*w tokens per frame)."""
+    identity = x
+    b, c, t, h, wd = x.shape
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, wd)
+    x = rms_norm(x, w[pre + ".norm.gamma"])
+    qkv = F.conv2d(x, w[pre + ".to_qkv.weight"], w[pre + ".to_qkv.bias"])
+    q, k, v = qkv.reshape(b * t, 1, c * 3, -1).permute(0, 1, 3, 2).contiguous().chunk(3, dim=-1)
+    x = F.scaled_dot_product_attention(q, k, v)
+    x = x.squeeze(1).permute(0, 2, 1).reshape(b * t, c, h, wd)
+    x = F.conv2d(x, w[pre + ".proj.weight"], w[pre + ".proj.bias"])
+    x = x.reshape(b, t, c, h, wd).permute(0, 2, 1, 3, 4)
+    return x + identity
+
+
+def resample_up(x, w, pre, mode, feat_cache, feat_idx):
+    """Resample.forward for 'upsample2d' / 'upsample3d', vae_block3.py:46-72 (same as vae.py:104-130)."""
+    b, c, t, h, wd = x.shape
+    if mode == "upsample3d":
+        idx = feat_idx[0]
+        if feat_cache[idx] is None:
+            feat_cache[idx] = torch.zeros(b, c, CACHE_T, h, wd, dtype=x.dtype, device=x.device)
+            feat_idx[0] += 1
+        else:
+            cache_x = x[:, :, -CACHE_T:].clone()
+            if cache_x.shape[2] < 2:
+                padding = torch.where(feat_cache[idx][:, :, -1:] == 0, 0, cache_x)
+                cache_x = torch.cat([padding, cache_x], dim=2)
+            x = causal_conv3d(x, w[pre + ".time_conv.weight"], w[pre + ".time_conv.bias"], (1, 0, 0), feat_cache[idx])
+            feat_cache[idx] = cache_x
+            feat_idx[0] += 1
+            x = x.reshape(b, 2, c, t, h, wd)
+            x = torch.stack((x[:, 0], x[:, 1]), 3).reshape(b, c, t * 2, h, wd)
+    t = x.shape[2]
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, wd)
+    x = F.interpolate(x.float(), scale_factor=(2.0, 2.0), mode="nearest").type_as(x)  # Upsample, vae.py:57-63
+    x = F.conv2d(x, w[pre + ".resample.1.weight"], w[pre + ".resample.1.bias"], padding=1)
+    return x.reshape(b, t, c // 2, 2 * h, 2 * wd).permute(0, 2, 1, 3, 4)
+
+
+def decoder3d(x, w, feat_cache):
+    """VAEDecoder3d.forward, vae_block3.py:386-443.  x: [B, 16, 1, h, w] (already through conv2)."""
+    feat_idx = [0]
+    x = _cached_conv(x, w, "decoder.conv1", feat_cache, feat_idx)
+    x = residual_block(x, w, "decoder.middle.0", feat_cache, feat_idx)
+    x = attention_block(x, w, "decoder.middle.1")
+    x = residual_block(x, w, "decoder.middle.2", feat_cache, feat_idx)
+    li = 0
+    for i in range(4):
+        for _ in range(3):
+            x = residual_block(x, w, f"decoder.upsamples.{li}", feat_cache, feat_idx)
+            li += 1
+        if i != 3:
+            x = resample_up(x, w, f"decoder.upsamples.{li}", "upsample3d" if i < 2 else "upsample2d",
+                            feat_cache, feat_idx)
+            li += 1
+    x = F.silu(rms_norm(x, w["decoder.head.0.gamma"]))
+    # head conv: the cache rule written out with an explicit zero slot (vae_block3.py:427-440)
+    idx = feat_idx[0]
+    b, c, t, h, wd = x.shape
+    cache_x = torch.zeros(b, c, CACHE_T, h, wd, dtype=x.dtype, device=x.device)
+    fill = x[:, :, -CACHE_T:].clone()
+    cache_x[:, :, -fill.shape[2]:] = fill
+    if fill.shape[2] < 2 and feat_cache[idx] is not None:
+        cache_x = torch.cat([feat_cache[idx][:, :, -1:], fill], dim=2)
+    x = causal_conv3d(x, w["decoder.head.2.weight"], w["decoder.head.2.bias"], (1, 1, 1), feat_cache[idx])
+    feat_cache[idx] = cache_x
+    feat_idx[0] += 1
+    return x, feat_cache
+
+
+def decoder_wrapper_forward(w, z, feat_cache):
+    """VAEDecoderWrapper.forward, vae_block3.py:195-230.  z: [B, T, 16, h, w]; feat_cache: list of 55
+    (Tensor | None).  Returns (pixels [B, T', 3, 8h, 8w] float32 in [-1, 1], feat_cache)."""
+    z = z.permute(0, 2, 1, 3, 4)
+    feat_cache = list(feat_cache)
+    mean = torch.tensor(MEAN, dtype=z.dtype, device=z.device).view(1, 16, 1, 1, 1)
+    inv_std = 1.0 / torch.tensor(STD, dtype=z.dtype, device=z.device).view(1, 16, 1, 1, 1)
+    z = z / inv_std + mean
+    x = causal_conv3d(z, w["conv2.weight"], w["conv2.bias"], (0, 0, 0))
+    outs = []
+    for i in range(x.shape[2]):
+        o, feat_cache = decoder3d(x[:, :, i:i + 1], w, feat_cache)
+        outs.append(o)
+    out = torch.cat(outs, 2).float().clamp_(-1, 1)
+    return out.permute(0, 2, 1, 3, 4), feat_cache
+
+
+def decoder_conv_specs():
+    """(state_dict prefix, kind, Cin, Cout) for every conv of the decoder in execution order."""
+    specs = [("decoder.conv1", "c3", 16, 384)]
+
+    def res(pre, cin, cout):
+        out = [(pre + ".residual.2", "c3", cin, cout), (pre + ".residual.6", "c3", cout, cout)]
+        if cin != cout:
+            out.append((pre + ".shortcut", "c1", cin, cout))
+        return out
+
+    specs += res("decoder.middle.0", 384, 384) + res("decoder.middle.2", 384, 384)
+    li, cin = 0, 384
+    for i, cout in enumerate(DIMS[1:]):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(3):
+            specs += res(f"decoder.upsamples.{li}", cin, cout)
+            cin = cout
+            li += 1
+        if i != 3:
+            if i < 2:
+                specs.append((f"decoder.upsamples.{li}.time_conv", "t3", cout, 2 * cout))
+            specs.append((f"decoder.upsamples.{li}.resample.1", "c2", cout, cout // 2))
+            li += 1
+    specs.append(("decoder.head.2", "c3", 96, 3))
+    return specs
+
+
+def make_vae_weights(seed=0, dtype=torch.float32):
+    """Deterministic synthetic decoder weights (there is no Wan2.1_VAE.pth offline): PyTorch-default-like
+    uniform conv init (bound 1/sqrt(fan_in)), gammas near 1, and a NON-zero attention proj (zero-init in
+    the reference, vae.py:227, would make the attention branch vanish)."""
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+
+    def conv(name, cout, cin, *k):
+        fan_in = cin * math.prod(k)
+        bound = 1.0 / math.sqrt(fan_in)
+        w[name + ".weight"] = (torch.rand(cout, cin, *k, generator=g) * 2 - 1) * bound
+        w[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
+
+    def gamma(name, c, dims):
+        w[name] = 1 + 0.1 * torch.randn(c, *([1] * dims), generator=g)
+
+    conv("conv2", 16, 16, 1, 1, 1)
+    for pre, kind, cin, cout in decoder_conv_specs():
+        if kind == "c3":
+            conv(pre, cout, cin, 3, 3, 3)
+        elif kind == "c1":
+            conv(pre, cout, cin, 1, 1, 1)
+        elif kind == "t3":
+            conv(pre, cout, cin, 3, 1, 1)
+        elif kind == "c2":
+            conv(pre, cout, cin, 3, 3)
+    # norms
+    def res_norms(pre, cin, cout):
+        gamma(pre + ".residual.0.gamma", cin, 3)
+        gamma(pre + ".residual.3.gamma", cout, 3)
+
+    res_norms("decoder.middle.0", 384, 384)
+    res_norms("decoder.middle.2", 384, 384)
+    gamma("decoder.middle.1.norm.gamma", 384, 2)
+    conv("decoder.middle.1.to_qkv", 384 * 3, 384, 1, 1)
+    conv("decoder.middle.1.proj", 384, 384, 1, 1)
+    li, cin = 0, 384
+    for i, cout in enumerate(DIMS[1:]):
+        if i in (1, 2, 3):
+            cin = cin // 2
+        for _ in range(3):
+            res_norms(f"decoder.upsamples.{li}", cin, cout)
+            cin = cout
+            li += 1
+        if i != 3:
+            li += 1
+    gamma("decoder.head.0.gamma", 96, 3)
+    return {k: v.to(dtype) for k, v in w.items()}

@@ -45,6 +45,13 @@ __device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
   f16x2 v = {(_Float16)lo, (_Float16)hi};
   return __builtin_bit_cast(uint32_t, v);
 }
+// NOTE: never __builtin_bit_cast a vector *element* expression (vec[j]) directly: hipcc (ROCm 7.2)
+// reinterprets the whole vector's first bytes instead.  Go through a scalar copy, as here.
+__device__ __forceinline__ void unpack_f16x2(uint32_t u, float& lo, float& hi) {
+  f16x2 h = __builtin_bit_cast(f16x2, u);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
 __device__ __forceinline__ float f16_to_f32(f16_t v) {
   _Float16 h;
   __builtin_memcpy(&h, &v, 2);

@@ -1,0 +1,493 @@
+// Streaming VAE decoder orchestrator + its HBM-bound kernels (fp16, channels-last).
+//
+// One call = VAEDecoderWrapper.forward (demo_utils/vae_block3.py:195-230): per latent frame run
+// VAEDecoder3d.forward (:386-443) = conv1 -> middle(Res, Attn, Res) -> 4 up stages (3 Res + Resample)
+// -> RMS_norm, SiLU, conv(96->3), with the 32 two-slice feature caches kept in a caller-owned arena.
+// Convolutions: vae_conv.hip.  1x1 convs / attention projections: the MFMA GEMM (gemm.hip, fp16).
+#include "gemm_core.h"
+#include "rtv_internal.h"
+
+namespace rtv {
+
+struct ConvParams;
+int launch_conv(const ConvParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------ RMS_norm (+SiLU), channels-last
+// F.normalize(x, dim=C) * sqrt(C) * gamma  (wan/modules/vae.py:39-54) followed by nn.SiLU.
+// 256 threads x 3 chunks of 8 channels = 768 chunks per block = 768/(C/8) whole pixels; the per-pixel
+// sum of squares is accumulated with LDS float atomics so every global access stays a coalesced 16 B.
+constexpr int RN_CHUNKS = 3;
+__global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ out,
+                                                             const f16_t* __restrict__ gamma, int C,
+                                                             int64_t npix, int apply_silu) {
+  __shared__ float ssq[64];
+  const int G = C >> 3;               // chunks per pixel (12 / 24 / 48)
+  const int ppb = (256 * RN_CHUNKS) / G;  // pixels per block
+  const int64_t pix0 = (int64_t)blockIdx.x * ppb;
+  if (threadIdx.x < 64) ssq[threadIdx.x] = 0.f;
+  __syncthreads();
+  float v[RN_CHUNKS][8];
+  int lp[RN_CHUNKS];
+#pragma unroll
+  for (int i = 0; i < RN_CHUNKS; ++i) {
+    const int c = threadIdx.x + i * 256;  // chunk id inside the block, < 768
+    lp[i] = c / G;
+    const int64_t pix = pix0 + lp[i];
+    float s = 0.f;
+    if (pix < npix) {
+      u32x4 raw = *(const u32x4*)(x + pix * C + (c - lp[i] * G) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t u = raw[j];
+        unpack_f16x2(u, v[i][2 * j], v[i][2 * j + 1]);
+        s += v[i][2 * j] * v[i][2 * j] + v[i][2 * j + 1] * v[i][2 * j + 1];
+      }
+      atomicAdd(&ssq[lp[i]], s);
+    }
+  }
+  __syncthreads();
+  const float sqrtC = sqrtf((float)C);
+#pragma unroll
+  for (int i = 0; i < RN_CHUNKS; ++i) {
+    const int c = threadIdx.x + i * 256;
+    const int64_t pix = pix0 + lp[i];
+    if (pix < npix) {
+      const int ch = (c - lp[i] * G) * 8;
+      const float inv = sqrtC / fmaxf(sqrtf(ssq[lp[i]]), 1e-12f);
+      u32x4 graw = *(const u32x4*)(gamma + ch);
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t gu = graw[j];
+        float g0, g1;
+        unpack_f16x2(gu, g0, g1);
+        float a = v[i][2 * j] * inv * g0;
+        float b = v[i][2 * j + 1] * inv * g1;
+        if (apply_silu) {
+          a = silu(a);
+          b = silu(b);
+        }
+        o[j] = pack_f16x2(a, b);
+      }
+      *(u32x4*)(out + pix * C + ch) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ row softmax (mid-block attention)
+// P[r][0..n) = softmax(S[r][0..n)) in f32, written f16 with zero padding up to ldp columns.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const f16_t* __restrict__ s, int lds_, f16_t* __restrict__ p,
+                                                          int ldp, int n) {
+  __shared__ float red[8];
+  const int row = blockIdx.x;
+  const f16_t* sr = s + (size_t)row * lds_;
+  f16_t* pr = p + (size_t)row * ldp;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x * 8; c < n; c += 256 * 8) {
+    u32x4 raw = *(const u32x4*)(sr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = raw[j];
+      float a, b;
+      unpack_f16x2(u, a, b);
+      mx = fmaxf(mx, fmaxf(a, b));
+    }
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = threadIdx.x * 8; c < n; c += 256 * 8) {
+    u32x4 raw = *(const u32x4*)(sr + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = raw[j];
+      float a, b;
+      unpack_f16x2(u, a, b);
+      sum += __expf(a - mx) + __expf(b - mx);
+    }
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = threadIdx.x * 8; c < ldp; c += 256 * 8) {
+    u32x4 o = {0u, 0u, 0u, 0u};
+    if (c < n) {
+      u32x4 raw = *(const u32x4*)(sr + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t u = raw[j];
+        float a, b;
+        unpack_f16x2(u, a, b);
+        o[j] = pack_f16x2(__expf(a - mx) * inv, __expf(b - mx) * inv);
+      }
+    }
+    *(u32x4*)(pr + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------ small glue kernels
+// Temporal-upsampling cache update for a single new slice (vae_block3.py:56-62):
+//   cache <- [ where(old_cache_last == 0, 0, x), x ]      buf = [c0 | c1 | x] (3 slices)
+__global__ void upsample_cache_t1_kernel(f16_t* buf, int64_t slice) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slice; i += (int64_t)gridDim.x * blockDim.x) {
+    f16_t c1 = buf[slice + i], x = buf[2 * slice + i];
+    buf[i] = ((c1 & 0x7fff) == 0) ? (f16_t)0 : x;
+    buf[slice + i] = x;
+  }
+}
+
+// z[T][16][h][w] (one latent frame t) -> conv2(z * std + mean) -> channels-last [h][w][32] (16 real + 16 zero)
+__global__ void vae_prep_kernel(const f16_t* __restrict__ z, int t, int hw, const float* __restrict__ mean,
+                                const float* __restrict__ stdv, const float* __restrict__ w2 /*[16][16]*/,
+                                const float* __restrict__ b2, f16_t* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= hw) return;
+  float zin[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    // reference order in fp16: z / (1/std) + mean   (vae_block3.py:206-211)
+    float zz = f16_to_f32(z[((size_t)t * 16 + c) * hw + p]);
+    float inv = round_f16(1.0f / round_f16(stdv[c]));
+    zin[c] = round_f16(round_f16(zz / inv) + round_f16(mean[c]));
+  }
+  u32x4 o[4];
+#pragma unroll
+  for (int co = 0; co < 16; co += 2) {
+    float a = b2[co], b = b2[co + 1];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      a += w2[co * 16 + c] * zin[c];
+      b += w2[(co + 1) * 16 + c] * zin[c];
+    }
+    o[co >> 3][(co & 7) >> 1] = pack_f16x2(a, b);
+  }
+  o[2] = u32x4{0u, 0u, 0u, 0u};
+  o[3] = u32x4{0u, 0u, 0u, 0u};
+  u32x4* dst = (u32x4*)(out + (size_t)p * 32);
+  dst[0] = o[0];
+  dst[1] = o[1];
+  dst[2] = o[2];
+  dst[3] = o[3];
+}
+
+// head output [T][H][W][8] f16 (3 real channels) -> pixels f32 [T][3][H][W], clamped to [-1, 1]
+__global__ void vae_final_kernel(const f16_t* __restrict__ in, float* __restrict__ out, int T, int64_t hw) {
+  const int64_t total = (int64_t)T * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / hw, p = i - t * hw;
+    u32x2 raw = *(const u32x2*)(in + i * 8);
+    const uint32_t u0 = raw[0], u1 = raw[1];
+    float c0, c1, c2, c3;
+    unpack_f16x2(u0, c0, c1);
+    unpack_f16x2(u1, c2, c3);
+    float r = fminf(fmaxf(c0, -1.f), 1.f), g = fminf(fmaxf(c1, -1.f), 1.f), bl = fminf(fmaxf(c2, -1.f), 1.f);
+    out[(t * 3 + 0) * hw + p] = r;
+    out[(t * 3 + 1) * hw + p] = g;
+    out[(t * 3 + 2) * hw + p] = bl;
+  }
+}
+
+}  // namespace rtv
+
+using namespace rtv;
+
+// ConvParams is defined in vae_conv.hip; the orchestrator goes through the C entry rtv_conv_cl.
+extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
+                           void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                           int ups, int n_split, const void* zeros, rtv_stream_t stream);
+
+#define RTV_TRY(expr)       \
+  do {                      \
+    int _s = (expr);        \
+    if (_s != 0) return _s; \
+  } while (0)
+
+extern "C" int rtv_rmsnorm_silu_cl(const void* x, void* out, const void* gamma, int C, int64_t npix, int apply_silu,
+                                   rtv_stream_t stream) {
+  if (npix <= 0) return 0;
+  if (C % 8 || 768 % (C / 8) || (768 / (C / 8)) > 64) return set_error(-1, "rmsnorm_silu_cl: C must be 96, 192, 384 (or another divisor layout of 768 chunks)");
+  const int ppb = 768 / (C / 8);
+  ProfScope prof(PROF_LN, (hipStream_t)stream, 2.0 * npix * C * 2);
+  hipLaunchKernelGGL(rmsnorm_silu_cl_kernel, dim3((unsigned)((npix + ppb - 1) / ppb)), dim3(256), 0,
+                     (hipStream_t)stream, (const f16_t*)x, (f16_t*)out, (const f16_t*)gamma, C, npix, apply_silu);
+  return check_launch("rmsnorm_silu_cl");
+}
+
+extern "C" int rtv_softmax_rows(const void* s, int lds_, void* p, int ldp, int rows, int n, rtv_stream_t stream) {
+  if (rows <= 0) return 0;
+  if (n % 8 || lds_ % 8 || ldp % 8 || ldp < n) return set_error(-1, "softmax_rows: n / strides must be multiples of 8");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const f16_t*)s, lds_,
+                     (f16_t*)p, ldp, n);
+  return check_launch("softmax_rows");
+}
+
+// ------------------------------------------------------------------ arena layout
+namespace {
+
+struct Stage {
+  int H, W;
+};
+
+struct VaeLayout {
+  // persistent: 32 concat buffers (2 cache slices + Tmax new slices each)
+  size_t cat_off[32];
+  int cat_C[32], cat_stage[32], cat_T[32];
+  size_t act_off[4];   // rotating activation buffers (max activation size)
+  size_t s_off, p_off, q_off, k_off, vt_off, o_off, xn_off;  // mid-block attention scratch
+  size_t head_off;     // [T][H][W][8]
+  size_t zeros_off;
+  size_t total;
+  int ldp;
+};
+
+// concat-buffer table in execution order: (channels, stage, Tmax)
+static void build_layout(int h, int w, VaeLayout* L) {
+  const int C[32] = {32, 384, 384, 384, 384,            // conv1, mid0.a, mid0.b, mid2.a, mid2.b
+                     384, 384, 384, 384, 384, 384, 384,   // up0 x3 (a,b), time_conv0
+                     192, 384, 384, 384, 384, 384, 384,   // up1: (192->384) a, b, then 384 x4, time_conv1
+                     192, 192, 192, 192, 192, 192,        // up2 x3
+                     96, 96, 96, 96, 96, 96, 96};         // up3 x3, head
+  const int S[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3};
+  const int Tm[4] = {1, 2, 4, 4};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    return a;
+  };
+  for (int i = 0; i < 32; ++i) {
+    const int s = S[i];
+    const size_t hw = (size_t)(h << s) * (w << s);
+    L->cat_C[i] = C[i];
+    L->cat_stage[i] = s;
+    L->cat_T[i] = Tm[s];
+    L->cat_off[i] = take((size_t)(2 + Tm[s]) * hw * C[i] * 2);
+  }
+  // largest activation: max over stages of T*H*W*C
+  size_t amax = 0;
+  const int actC[4] = {768, 768, 384, 192};  // widest tensor living at each stage (time_conv output counted at source res)
+  for (int s = 0; s < 4; ++s) {
+    size_t hw = (size_t)(h << s) * (w << s);
+    size_t b = (size_t)Tm[s] * hw * actC[s] * 2;
+    if (b > amax) amax = b;
+  }
+  {
+    size_t hw3 = (size_t)(h << 3) * (w << 3);
+    size_t b = (size_t)4 * hw3 * 96 * 2;
+    if (b > amax) amax = b;
+  }
+  for (int i = 0; i < 4; ++i) L->act_off[i] = take(amax);
+  const size_t P = (size_t)h * w;
+  L->ldp = (int)((P + 63) / 64 * 64);
+  L->s_off = take(P * P * 2);
+  L->p_off = take(P * (size_t)L->ldp * 2);
+  L->q_off = take(P * 384 * 2);
+  L->k_off = take(P * 384 * 2);
+  L->vt_off = take((size_t)384 * L->ldp * 2);
+  L->o_off = take(P * 384 * 2);
+  L->xn_off = take(P * 384 * 2);
+  L->head_off = take((size_t)4 * (h << 3) * (w << 3) * 8 * 2);
+  L->zeros_off = take(256);
+  L->total = off + 256;
+}
+
+}  // namespace
+
+extern "C" size_t rtv_vae_arena_bytes(int h, int w) {
+  if (h <= 0 || w <= 0) return 0;
+  VaeLayout L;
+  build_layout(h, w, &L);
+  return L.total;
+}
+
+/* byte offset + slice geometry of feature-cache slot i (0..31) inside the arena: the two cached slices
+ * are the first two [H][W][C] slices of the conv's concat buffer. */
+extern "C" int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, int* W) {
+  if (slot < 0 || slot >= 32) return set_error(-1, "vae_cache_slot: slot out of range");
+  VaeLayout L;
+  build_layout(h, w, &L);
+  *offset = L.cat_off[slot];
+  *C = L.cat_C[slot];
+  *H = h << L.cat_stage[slot];
+  *W = w << L.cat_stage[slot];
+  return 0;
+}
+
+namespace {
+
+struct Ctx {
+  const rtv_vae_weights* w;
+  char* arena;
+  const VaeLayout* L;
+  int h, wd;
+  hipStream_t stream;
+  int act_next;
+  uint16_t* act(int i) { return (uint16_t*)(arena + L->act_off[i & 3]); }
+  uint16_t* cat(int i) { return (uint16_t*)(arena + L->cat_off[i]); }
+  const void* zeros() { return arena + L->zeros_off; }
+};
+
+// conv over concat buffer `ci` whose slices [2, 2+T) already hold the new input; then roll the cache.
+static int cached_conv3(Ctx& c, int ci, int T, int H, int W, int Cin, const rtv_vae_conv& cw, int Cout,
+                        const void* residual, void* out, int out_ld) {
+  uint16_t* buf = c.cat(ci);
+  RTV_TRY(rtv_conv_cl(buf, cw.w, cw.b, residual, Cout, out, out_ld, T, H, W, Cin, Cout, 3, 3, 3, 0, 0, c.zeros(),
+                      c.stream));
+  const size_t slice = (size_t)H * W * Cin * 2;
+  char* b = (char*)buf;
+  if (T == 1) {
+    if (hipMemcpyAsync(b, b + slice, slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess ||
+        hipMemcpyAsync(b + slice, b + 2 * slice, slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+      return set_error(-1, "vae: cache roll memcpy failed");
+  } else {
+    if (hipMemcpyAsync(b, b + (size_t)T * slice, 2 * slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+      return set_error(-1, "vae: cache roll memcpy failed");
+  }
+  return 0;
+}
+
+// ResidualBlock (wan/modules/vae.py:175-209): x [T][H][W][cin] -> y [T][H][W][cout]
+static int res_block(Ctx& c, int ci, int T, int H, int W, int cin, int cout, const rtv_vae_res& rw,
+                     const uint16_t* x, uint16_t* tmp, uint16_t* sc_buf, uint16_t* y) {
+  const int64_t npix = (int64_t)T * H * W;
+  const size_t sl_in = (size_t)H * W * cin, sl_out = (size_t)H * W * cout;
+  RTV_TRY(rtv_rmsnorm_silu_cl(x, c.cat(ci) + 2 * sl_in, rw.gamma0, cin, npix, 1, c.stream));
+  RTV_TRY(cached_conv3(c, ci, T, H, W, cin, rw.conv_a, cout, nullptr, tmp, cout));
+  RTV_TRY(rtv_rmsnorm_silu_cl(tmp, c.cat(ci + 1) + 2 * sl_out, rw.gamma3, cout, npix, 1, c.stream));
+  const uint16_t* hres = x;
+  if (rw.shortcut.w) {  // 1x1x1 conv = plain GEMM over pixels
+    RTV_TRY(rtv_gemm(x, cin, rw.shortcut.w, cin, sc_buf, cout, (int)npix, cout, cin, rw.shortcut.b, 0, nullptr, 0, 0,
+                     nullptr, 0, RTV_DTYPE_F16, 0, c.stream));
+    hres = sc_buf;
+  }
+  RTV_TRY(cached_conv3(c, ci + 1, T, H, W, cout, rw.conv_b, cout, hres, y, cout));
+  return 0;
+}
+
+// AttentionBlock (wan/modules/vae.py:212-251) on one frame: x [P][384] -> y [P][384]
+static int mid_attention(Ctx& c, const uint16_t* x, uint16_t* y) {
+  const rtv_vae_attn& a = c.w->attn;
+  const int P = c.h * c.wd, C = 384, ldp = c.L->ldp;
+  char* A = c.arena;
+  uint16_t *S = (uint16_t*)(A + c.L->s_off), *Pm = (uint16_t*)(A + c.L->p_off), *q = (uint16_t*)(A + c.L->q_off),
+           *k = (uint16_t*)(A + c.L->k_off), *vt = (uint16_t*)(A + c.L->vt_off), *o = (uint16_t*)(A + c.L->o_off),
+           *xn = (uint16_t*)(A + c.L->xn_off);
+  auto G = [&](const void* a_, int lda, const void* w_, int ldw, void* out, int ldc, int M, int N, int K,
+               const void* bias, const void* res, int ldr) {
+    return rtv_gemm(a_, lda, w_, ldw, out, ldc, M, N, K, bias, 0, nullptr, 0, 0, res, ldr, RTV_DTYPE_F16, 0, c.stream);
+  };
+  RTV_TRY(rtv_rmsnorm_silu_cl(x, xn, a.gamma, C, P, 0, c.stream));
+  RTV_TRY(G(xn, C, a.wq, C, q, C, P, C, C, a.bq, nullptr, 0));      // wq/bq carry the 1/sqrt(C) softmax scale
+  RTV_TRY(G(xn, C, a.wk, C, k, C, P, C, C, a.bk, nullptr, 0));
+  RTV_TRY(G(a.wv, C, xn, C, vt, ldp, C, P, C, nullptr, nullptr, 0)); // V^T [C][P] (bias folded below: rows of P sum to 1)
+  RTV_TRY(G(q, C, k, C, S, P, P, P, C, nullptr, nullptr, 0));        // S = q k^T
+  RTV_TRY(rtv_softmax_rows(S, P, Pm, ldp, P, P, c.stream));
+  RTV_TRY(G(Pm, ldp, vt, ldp, o, C, P, C, ldp, a.bv, nullptr, 0));   // O = P V + bv
+  RTV_TRY(G(o, C, a.wproj, C, y, C, P, C, C, a.bproj, x, C));        // proj + identity
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, void* arena,
+                              size_t arena_bytes, void* pixels, rtv_stream_t stream_) {
+  if (!w || !z || !arena || !pixels) return set_error(-1, "vae_decode: null argument");
+  if (T <= 0) return 0;
+  if ((h * wd) % 8) return set_error(-1, "vae_decode: h*w must be a multiple of 8");
+  if (((uintptr_t)arena) & 255) return set_error(-1, "vae_decode: arena must be 256-byte aligned");
+  VaeLayout L;
+  build_layout(h, wd, &L);
+  if (arena_bytes < L.total) return set_error(-1, "vae_decode: arena too small (see rtv_vae_arena_bytes)");
+  hipStream_t stream = (hipStream_t)stream_;
+  Ctx c{w, (char*)arena, &L, h, wd, stream, 0};
+  const int64_t HW8 = (int64_t)(h * 8) * (wd * 8);
+  int out_frame = 0;
+  // V^T pad columns (K padding of the P.V GEMM) must be zero
+  if (L.ldp != h * wd)
+    if (hipMemsetAsync((char*)arena + L.vt_off, 0, (size_t)384 * L.ldp * 2, stream) != hipSuccess)
+      return set_error(-1, "vae_decode: memset failed");
+
+  for (int f = 0; f < T; ++f) {
+    const bool is_first = first && f == 0;
+    int H = h, W = wd, Tn = 1;
+    uint16_t *a0 = c.act(0), *a1 = c.act(1), *a2 = c.act(2), *a3 = c.act(3);
+    // conv2 (1x1x1, 16->16) + de-normalisation, written into conv1's concat buffer (32-channel padded)
+    {
+      const size_t sl = (size_t)H * W * 32;
+      hipLaunchKernelGGL(vae_prep_kernel, dim3((H * W + 127) / 128), dim3(128), 0, stream, (const f16_t*)z, f, H * W,
+                         (const float*)w->mean, (const float*)w->std, (const float*)w->conv2_w,
+                         (const float*)w->conv2_b, (f16_t*)(c.cat(0) + 2 * sl));
+      RTV_TRY(check_launch("vae_prep"));
+    }
+    RTV_TRY(cached_conv3(c, 0, 1, H, W, 32, w->conv1, 384, nullptr, a0, 384));
+    RTV_TRY(res_block(c, 1, 1, H, W, 384, 384, w->mid0, a0, a1, a2, a3));
+    RTV_TRY(mid_attention(c, a3, a0));
+    RTV_TRY(res_block(c, 3, 1, H, W, 384, 384, w->mid2, a0, a1, a2, a3));
+    uint16_t* x = a3;  // current activation; the other three buffers are free
+    int ci = 5;
+    for (int s = 0; s < 4; ++s) {
+      const int cout = (s == 0 || s == 1) ? 384 : (s == 2 ? 192 : 96);
+      int cin = (s == 0) ? 384 : (s == 1 ? 192 : (s == 2 ? 192 : 96));
+      for (int r = 0; r < 3; ++r) {
+        uint16_t* bufs[3];
+        int nb = 0;
+        for (int i = 0; i < 4; ++i)
+          if (c.act(i) != x) bufs[nb++] = c.act(i);
+        RTV_TRY(res_block(c, ci, Tn, H, W, cin, cout, w->up[s * 3 + r], x, bufs[0], bufs[1], bufs[2]));
+        x = bufs[2];
+        ci += 2;
+        cin = cout;
+      }
+      if (s == 3) break;
+      uint16_t* free_[3];
+      int nb = 0;
+      for (int i = 0; i < 4; ++i)
+        if (c.act(i) != x) free_[nb++] = c.act(i);
+      if (s < 2) {  // upsample3d: temporal doubling through time_conv, skipped for the very first frame
+        const size_t sl = (size_t)H * W * cout;
+        uint16_t* buf = c.cat(ci);
+        if (!is_first) {
+          if (hipMemcpyAsync(buf + 2 * sl, x, (size_t)Tn * sl * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+            return set_error(-1, "vae_decode: memcpy failed");
+          RTV_TRY(rtv_conv_cl(buf, w->time_conv[s].w, w->time_conv[s].b, nullptr, 0, free_[0], cout, Tn, H, W, cout,
+                              2 * cout, 3, 1, 1, 0, cout, c.zeros(), stream));
+          if (Tn == 1) {
+            hipLaunchKernelGGL(upsample_cache_t1_kernel, dim3(1024), dim3(256), 0, stream, (f16_t*)buf, (int64_t)sl);
+            RTV_TRY(check_launch("upsample_cache_t1"));
+          } else {
+            if (hipMemcpyAsync(buf, buf + (size_t)Tn * sl, 2 * sl * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+              return set_error(-1, "vae_decode: memcpy failed");
+          }
+          x = free_[0];
+          Tn *= 2;
+          nb = 0;
+          for (int i = 0; i < 4; ++i)
+            if (c.act(i) != x) free_[nb++] = c.act(i);
+        }
+        ci += 1;
+      }
+      // nearest 2x + Conv2d 3x3 (cout -> cout/2), per frame
+      RTV_TRY(rtv_conv_cl(x, w->resample[s].w, w->resample[s].b, nullptr, 0, free_[0], cout / 2, Tn, 2 * H, 2 * W, cout,
+                          cout / 2, 1, 3, 3, 1, 0, c.zeros(), stream));
+      x = free_[0];
+      H *= 2;
+      W *= 2;
+    }
+    // head: RMS_norm, SiLU, conv 96 -> 3 (filters padded to 8)
+    {
+      const size_t sl = (size_t)H * W * 96;
+      RTV_TRY(rtv_rmsnorm_silu_cl(x, c.cat(31) + 2 * sl, w->head_gamma, 96, (int64_t)Tn * H * W, 1, stream));
+      uint16_t* ho = (uint16_t*)((char*)arena + L.head_off);
+      RTV_TRY(cached_conv3(c, 31, Tn, H, W, 96, w->head, 8, nullptr, ho, 8));
+      hipLaunchKernelGGL(vae_final_kernel, dim3(2048), dim3(256), 0, stream, (const f16_t*)ho,
+                         (float*)pixels + (size_t)out_frame * 3 * HW8, Tn, HW8);
+      RTV_TRY(check_launch("vae_final"));
+      out_frame += Tn;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,206 @@
+"""Mirror of the reference's streaming `VAEDecoderWrapper` (demo_utils/vae_block3.py:177-230):
+
+    pixels, feat_cache = decoder(z[B,T,16,h,w] fp16, *feat_cache)     # feat_cache: 55 x (Tensor | None)
+
+backed by the native `rtv_vae_decode` (include/rtv_hip.h): implicit-GEMM causal convolutions with the
+feature-cache concat, nearest-2x upsampling, temporal-upsampling scatter and residual adds fused in.
+State-dict keys are the reference's (`decoder.*`, `conv2.*`, loaded from Wan2.1_VAE.pth in
+release_server.py:204-215).  The 32 live cache slots returned are *views* into one arena allocation
+(channels-last in memory, exposed in the reference's [1, C, 2, H, W] shape); passing the list back
+continues the stream, passing `[None] * 55` starts a new one.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+c_vp = ctypes.c_void_p
+
+
+class _Conv(ctypes.Structure):
+    _fields_ = [("w", c_vp), ("b", c_vp)]
+
+
+class _Res(ctypes.Structure):
+    _fields_ = [("gamma0", c_vp), ("conv_a", _Conv), ("gamma3", c_vp), ("conv_b", _Conv), ("shortcut", _Conv)]
+
+
+class _Attn(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("gamma", "wq", "bq", "wk", "bk", "wv", "bv", "wproj", "bproj")]
+
+
+class _VaeWeights(ctypes.Structure):
+    _fields_ = [("conv2_w", c_vp), ("conv2_b", c_vp), ("mean", c_vp), ("std", c_vp), ("conv1", _Conv),
+                ("mid0", _Res), ("mid2", _Res), ("up", _Res * 12), ("attn", _Attn),
+                ("time_conv", _Conv * 2), ("resample", _Conv * 3), ("head_gamma", c_vp), ("head", _Conv)]
+
+
+_lib.EXTRA_SIGNATURES.update({
+    "rtv_conv_cl": [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int] + [ctypes.c_int] * 10 + [c_vp, c_vp],
+    "rtv_rmsnorm_silu_cl": [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_vp],
+    "rtv_softmax_rows": [c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp],
+    "rtv_vae_decode": [ctypes.POINTER(_VaeWeights), c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                       c_vp, ctypes.c_size_t, c_vp, c_vp],
+    "rtv_vae_cache_slot": [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
+                           ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+})
+
+MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
+        0.4134, -0.0715, 0.5517, -0.3632, -0.1922, -0.9497, 0.2503, -0.2921]
+STD = [2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
+       3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160]
+
+
+def pack_conv_weight(w, cin_pad=None, cout_pad=None):
+    """torch conv weight [Cout, Cin, *k] -> fp16 [Cout][taps][Cin] (K-contiguous im2col order)."""
+    w = w.detach().to(torch.float16)
+    nd = w.dim() - 2
+    perm = [0] + list(range(2, 2 + nd)) + [1]
+    w = w.permute(*perm).contiguous()
+    cout, cin = w.shape[0], w.shape[-1]
+    w = w.reshape(cout, -1, cin)
+    if cin_pad and cin_pad > cin:
+        w = torch.cat([w, w.new_zeros(cout, w.shape[1], cin_pad - cin)], dim=2)
+    if cout_pad and cout_pad > cout:
+        w = torch.cat([w, w.new_zeros(cout_pad - cout, w.shape[1], w.shape[2])], dim=0)
+    return w.contiguous()
+
+
+class VAEDecoderWrapper:
+    z_dim = 16
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self._t = {}
+        self._w = None
+        self._arena_bytes = {}
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict=True):
+        dev, f16 = self.device, torch.float16
+        t = {}
+        W = _VaeWeights()
+
+        def dv(x):
+            return x.to(dev).contiguous()
+
+        def conv(dst, name, cin_pad=None, cout_pad=None):
+            wt = dv(pack_conv_weight(sd[name + ".weight"], cin_pad, cout_pad))
+            b = sd[name + ".bias"].detach().to(f16)
+            if cout_pad and cout_pad > b.numel():
+                b = torch.cat([b, b.new_zeros(cout_pad - b.numel())])
+            b = dv(b)
+            t[name + ".w"], t[name + ".b"] = wt, b
+            dst.w, dst.b = wt.data_ptr(), b.data_ptr()
+
+        def gam(name):
+            g = dv(sd[name].detach().to(f16).reshape(-1))
+            t[name] = g
+            return g.data_ptr()
+
+        def res(dst, pre):
+            dst.gamma0 = gam(pre + ".residual.0.gamma")
+            conv(dst.conv_a, pre + ".residual.2")
+            dst.gamma3 = gam(pre + ".residual.3.gamma")
+            conv(dst.conv_b, pre + ".residual.6")
+            if pre + ".shortcut.weight" in sd:
+                conv(dst.shortcut, pre + ".shortcut")
+            else:
+                dst.shortcut.w, dst.shortcut.b = None, None
+
+        for nm, val in (("mean", MEAN), ("std", STD)):
+            t[nm] = torch.tensor(val, dtype=torch.float32, device=dev)
+        t["conv2_w"] = dv(sd["conv2.weight"].detach().to(f16).float().reshape(16, 16))
+        t["conv2_b"] = dv(sd["conv2.bias"].detach().to(f16).float())
+        W.conv2_w, W.conv2_b = t["conv2_w"].data_ptr(), t["conv2_b"].data_ptr()
+        W.mean, W.std = t["mean"].data_ptr(), t["std"].data_ptr()
+        conv(W.conv1, "decoder.conv1", cin_pad=32)
+        res(W.mid0, "decoder.middle.0")
+        res(W.mid2, "decoder.middle.2")
+        # attention (single head, C = 384): fold the softmax scale into the query projection
+        C = 384
+        pre = "decoder.middle.1"
+        W.attn.gamma = gam(pre + ".norm.gamma")
+        qkv_w = sd[pre + ".to_qkv.weight"].detach().to(f16).float().reshape(3 * C, C)
+        qkv_b = sd[pre + ".to_qkv.bias"].detach().to(f16).float()
+        sc = 1.0 / math.sqrt(C)
+        parts = {"wq": qkv_w[:C] * sc, "bq": qkv_b[:C] * sc, "wk": qkv_w[C:2 * C], "bk": qkv_b[C:2 * C],
+                 "wv": qkv_w[2 * C:], "bv": qkv_b[2 * C:],
+                 "wproj": sd[pre + ".proj.weight"].detach().float().reshape(C, C), "bproj": sd[pre + ".proj.bias"].detach().float()}
+        for k, v in parts.items():
+            t["attn." + k] = dv(v.to(f16))
+            setattr(W.attn, k, t["attn." + k].data_ptr())
+        li = 0
+        for s in range(4):
+            for r in range(3):
+                res(W.up[s * 3 + r], f"decoder.upsamples.{li}")
+                li += 1
+            if s != 3:
+                if s < 2:
+                    conv(W.time_conv[s], f"decoder.upsamples.{li}.time_conv")
+                conv(W.resample[s], f"decoder.upsamples.{li}.resample.1")
+                li += 1
+        W.head_gamma = gam("decoder.head.0.gamma")
+        conv(W.head, "decoder.head.2", cout_pad=8)
+        self._t, self._w = t, W
+        return [], []
+
+    # ------------------------------------------------------------------ arena / cache views
+    def _new_arena(self, h, w):
+        lib = _lib.load()
+        lib.rtv_vae_arena_bytes.restype = ctypes.c_size_t
+        lib.rtv_vae_arena_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        n = lib.rtv_vae_arena_bytes(h, w)
+        return torch.zeros(n + 256, dtype=torch.uint8, device=self.device)
+
+    def _cache_views(self, arena, base, h, w):
+        views = [None] * 55
+        off, C, H, Wd = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        for i in range(32):
+            _lib.call("rtv_vae_cache_slot", h, w, i, ctypes.byref(off), ctypes.byref(C), ctypes.byref(H), ctypes.byref(Wd))
+            n = 2 * H.value * Wd.value * C.value
+            start = base + off.value
+            flat = arena[start:start + n * 2].view(torch.float16)
+            v = flat.view(2, H.value, Wd.value, C.value)
+            if i == 0:
+                v = v[..., :16]
+            views[i] = v.permute(3, 0, 1, 2).unsqueeze(0)   # [1, C, 2, H, W] like the reference
+        views[0]._rtv_arena = (arena, base)
+        return views
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, z, *feat_cache):
+        if self._w is None:
+            raise RuntimeError("weights not loaded")
+        if not z.is_cuda:
+            raise RuntimeError("realtime_video_amd.VAEDecoderWrapper needs GPU tensors (no CPU fallback)")
+        B, T, C, h, w = z.shape
+        if B != 1 or C != 16:
+            raise NotImplementedError("VAE decoder: batch 1, 16 latent channels")
+        zz = z[0].to(torch.float16).contiguous()
+        first = len(feat_cache) == 0 or feat_cache[0] is None
+        if first:
+            arena = self._new_arena(h, w)
+            base = (-arena.data_ptr()) % 256
+        else:
+            arena, base = feat_cache[0]._rtv_arena
+        n_out = 4 * T - 3 if first else 4 * T
+        pixels = torch.empty((n_out, 3, 8 * h, 8 * w), dtype=torch.float32, device=z.device)
+        _lib.call("rtv_vae_decode", ctypes.byref(self._w), c_vp(zz.data_ptr()), T, h, w, int(first),
+                  c_vp(arena.data_ptr() + base), ctypes.c_size_t(arena.numel() - base), c_vp(pixels.data_ptr()),
+                  c_vp(torch.cuda.current_stream().cuda_stream))
+        cache = list(feat_cache) if not first else self._cache_views(arena, base, h, w)
+        return pixels.unsqueeze(0), cache
+
+    __call__ = forward

@@ -1,0 +1,141 @@
+"""VAE decoder parity on the MI355X (through the C ABI): implicit-GEMM convolution vs torch fp32
+convolutions, fused RMS_norm+SiLU / softmax kernels, and the full streaming decoder vs golden pixels
+minted from the upstream VAEDecoderWrapper (fp32 CPU).  Stated tolerance: fp16 pipeline vs fp32
+reference, max-abs <= 2e-2 on pixels in [-1, 1]."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_abs, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _conv_cl(inp, w, bias, T, H, W, kt, kh, kw, ups=0, n_split=0, residual=None):
+    """inp: channels-last concat buffer [Tin][inH][inW][Cin] fp16; w: torch conv weight."""
+    from realtime_video_amd import _lib
+    from realtime_video_amd.vae_decoder import pack_conv_weight
+    import realtime_video_amd.vae_decoder  # noqa: F401  (registers signatures)
+    wp = pack_conv_weight(w).to(DEV)
+    Cout, Cin = wp.shape[0], wp.shape[2]
+    zeros = torch.zeros(64, dtype=torch.float16, device=DEV)
+    if n_split:
+        out = torch.empty(2 * T, H, W, n_split, dtype=torch.float16, device=DEV)
+        out_ld = n_split
+    else:
+        out = torch.empty(T, H, W, Cout, dtype=torch.float16, device=DEV)
+        out_ld = Cout
+    _lib.call("rtv_conv_cl", _p(inp), _p(wp), _p(bias), _p(residual), Cout, _p(out), out_ld, T, H, W, Cin, Cout,
+              kt, kh, kw, ups, n_split, _p(zeros), _stream())
+    return out
+
+
+@pytest.mark.parametrize("Cin,Cout", [(32, 384), (96, 96), (192, 192), (384, 384), (96, 8), (192, 384)])
+@pytest.mark.parametrize("T,H,W", [(1, 8, 12), (4, 16, 24)])
+def test_causal_conv3d_with_cache_concat(Cin, Cout, T, H, W):
+    g = torch.Generator().manual_seed(Cin + Cout + T)
+    x = torch.randn(T + 2, H, W, Cin, generator=g).half().to(DEV)          # [2 cached | T new]
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
+    res = torch.randn(T, H, W, Cout, generator=g).half().to(DEV)
+    out = _conv_cl(x, w, b, T, H, W, 3, 3, 3, residual=res)
+    xin = x.permute(3, 0, 1, 2).unsqueeze(0).float()                        # [1, C, T+2, H, W]
+    ref = F.conv3d(F.pad(xin, (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+    ref = (ref.half().float() + res.float())
+    assert out.shape == ref.shape
+    assert max_abs(out, ref) <= 1e-2 and rel_l2(out, ref) <= 2e-3
+
+
+def test_upsample_conv2d_and_time_conv():
+    g = torch.Generator().manual_seed(3)
+    T, H, W, C = 2, 6, 10, 192
+    x = torch.randn(T, H, W, C, generator=g).half().to(DEV)
+    w = (torch.randn(C // 2, C, 3, 3, generator=g) * (9 * C) ** -0.5).half().to(DEV)
+    b = (torch.randn(C // 2, generator=g) * 0.1).half().to(DEV)
+    out = _conv_cl(x, w, b, T, 2 * H, 2 * W, 1, 3, 3, ups=1)
+    xin = x.permute(0, 3, 1, 2).float()
+    ref = F.conv2d(F.interpolate(xin, scale_factor=(2.0, 2.0), mode="nearest"), w.float(), b.float(), padding=1)
+    assert max_abs(out, ref.permute(0, 2, 3, 1)) <= 1e-2
+    # time_conv (3,1,1), C -> 2C, channel halves interleaved into frames (vae_block3.py:61-67)
+    C = 384
+    xc = torch.randn(T + 2, H, W, C, generator=g).half().to(DEV)
+    wt = (torch.randn(2 * C, C, 3, 1, 1, generator=g) * (3 * C) ** -0.5).half().to(DEV)
+    bt = (torch.randn(2 * C, generator=g) * 0.1).half().to(DEV)
+    out = _conv_cl(xc, wt, bt, T, H, W, 3, 1, 1, n_split=C)
+    y = F.conv3d(xc.permute(3, 0, 1, 2).unsqueeze(0).float(), wt.float(), bt.float())   # [1, 2C, T, H, W]
+    y = y.reshape(1, 2, C, T, H, W)
+    y = torch.stack((y[:, 0], y[:, 1]), 3).reshape(1, C, 2 * T, H, W)[0].permute(1, 2, 3, 0)
+    assert out.shape == y.shape and max_abs(out, y) <= 1e-2
+
+
+@pytest.mark.parametrize("C", [96, 192, 384])
+def test_rmsnorm_silu_channels_last(C):
+    from realtime_video_amd import _lib
+    import realtime_video_amd.vae_decoder  # noqa: F401
+    g = torch.Generator().manual_seed(C)
+    npix = 1000
+    x = (torch.randn(npix, C, generator=g) * 3).half().to(DEV)
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).half().to(DEV)
+    for silu in (1, 0):
+        out = torch.empty_like(x)
+        _lib.call("rtv_rmsnorm_silu_cl", _p(x), _p(out), _p(gamma), C, npix, silu, _stream())
+        ref = F.normalize(x.float(), dim=1) * C ** 0.5 * gamma.float()
+        if silu:
+            ref = F.silu(ref)
+        assert max_abs(out, ref) <= 4e-3
+
+
+def test_softmax_rows():
+    from realtime_video_amd import _lib
+    import realtime_video_amd.vae_decoder  # noqa: F401
+    n, ldp = 96, 128
+    s = (torch.randn(n, n) * 3).half().to(DEV)
+    p = torch.full((n, ldp), 7.0, dtype=torch.float16, device=DEV)
+    _lib.call("rtv_softmax_rows", _p(s), n, _p(p), ldp, n, n, _stream())
+    assert max_abs(p[:, :n], torch.softmax(s.float(), -1)) <= 1e-3
+    assert float(p[:, n:].abs().max()) == 0
+
+
+def test_streaming_decoder_matches_reference_golden(golden):
+    from oracle import vae_oracle as vo
+    from oracle.make_golden import vae_inputs
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    g = golden("vae_decoder.pt")
+    dec = VAEDecoderWrapper(DEV)
+    dec.load_state_dict(vo.make_vae_weights(seed=0))
+    cache = [None] * 55
+    # the reference's own precision: the same graph in eager fp16 on this GPU (what release_server.py runs)
+    w16 = {k: v.half().to(DEV) for k, v in vo.make_vae_weights(seed=0).items()}
+    cache16 = [None] * 55
+    for i, z in enumerate(vae_inputs()):
+        px, cache = dec(z.half().to(DEV), *cache)
+        ref = g["pixels"][i]
+        assert px.shape == ref.shape and px.dtype == torch.float32
+        px16, cache16 = vo.decoder_wrapper_forward(w16, z.half().to(DEV), cache16)
+        err, err16 = max_abs(px.cpu(), ref), max_abs(px16.cpu(), ref)
+        mean_err = float((px.cpu() - ref).abs().mean())
+        # stated tolerance: within 2x the eager-fp16 reference error (+ floor), hard cap 5e-2 on [-1, 1] pixels
+        assert err <= max(2 * err16, 2e-2) and err <= 5e-2, (i, err, err16)
+        assert mean_err <= 2e-3, (i, mean_err)
+        assert float(px.abs().max()) <= 1.0
+    assert len(cache) == 55 and sum(c is not None for c in cache) == 32
+    for c, shp in zip(cache, g["cache_shapes"][-1]):
+        if c is not None:
+            assert tuple(c.shape) == shp
+    for c, gs in zip(cache, g["cache_sample"]):
+        if c is not None:
+            assert rel_l2(c[0, ::7, :, ::3, ::5].float().cpu(), gs) <= 2e-2
+    # a fresh stream restarts from the 9-frame first block
+    px, _ = dec(vae_inputs()[0].half().to(DEV), *([None] * 55))
+    assert px.shape[1] == 9 and max_abs(px.cpu(), g["pixels"][0]) <= 3e-2

@@ -1,0 +1,32 @@
+"""Pins the CPU VAE-decoder oracle (oracle/vae_oracle.py) against goldens minted from the upstream
+reference's VAEDecoderWrapper (oracle/make_golden.py golden_vae).  CPU only."""
+import torch
+
+from conftest import max_abs
+
+from oracle import vae_oracle as vo
+from oracle.make_golden import vae_inputs
+
+
+def test_vae_decoder_streaming_matches_reference(golden):
+    g = golden("vae_decoder.pt")
+    w = vo.make_vae_weights(seed=0)
+    cs = float(sum(v.double().abs().sum() for v in w.values()))
+    assert abs(cs - g["weights_checksum"]) <= 1e-6 * g["weights_checksum"]
+    cache = [None] * 55
+    for i, z in enumerate(vae_inputs()):
+        px, cache = vo.decoder_wrapper_forward(w, z, cache)
+        assert px.shape == g["pixels"][i].shape and px.dtype == torch.float32
+        assert max_abs(px, g["pixels"][i]) <= 1e-4, i
+        shapes = [None if c is None else tuple(c.shape) for c in cache]
+        assert shapes == g["cache_shapes"][i]
+    assert [p.shape[1] for p in g["pixels"]] == [9, 12, 12]   # first block: 1 + 4 + 4 frames
+    assert sum(c is not None for c in cache) == 32             # 32 cached convs (demo_utils/constant.py:6-39)
+    for c, gs in zip(cache, g["cache_sample"]):
+        if c is not None:
+            assert max_abs(c[0, ::7, :, ::3, ::5], gs) <= 1e-4
+
+
+def test_decoder_conv_inventory():
+    specs = vo.decoder_conv_specs()
+    assert sum(k in ("c3", "t3") for _, k, _, _ in specs) == 32 and sum(k == "c1" for _, k, _, _ in specs) == 1
