@@ -1,0 +1,200 @@
+"""Headline benchmark: frames/sec at 832x480, 4 denoising steps, Krea-Realtime-14B-shaped causal Wan DiT
+(random-init weights of the 14B architecture, synthetic latents / prompt embeddings) + streaming VAE
+decode, driven by the GenerationSession block loop — BASELINE.json `configs[2]`.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one generated block = KV-recompute forward + 4 denoise forwards + VAE decode of 3 latent
+frames = 12 output frames.  Prints ONE JSON line on rank 0 (see README / DESIGN.md §Measurement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODELS = {
+    "14b": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, name="Krea-Realtime-14B (Wan2.1-T2V-14B arch)"),
+    "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, name="Wan2.1-T2V-1.3B arch"),
+}
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(model_cfg, seconds_budget=30.0):
+    """The CPU oracle (port of the reference's eager path) timed on this host's cores on a bounded sample:
+    ONE DiT layer of the benchmarked width at the real token counts (M=4680 queries, 9360 cached keys),
+    extrapolated to a block (40 layers x (4 denoise + 0.88 recompute-equivalent) forwards), DiT only."""
+    from oracle import wan_oracle as wo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    d, ffn, H = model_cfg["dim"], model_cfg["ffn_dim"], model_cfg["num_heads"]
+    cfg = dict(dim=d, ffn_dim=ffn, num_heads=H, num_layers=1)
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    for a in ("self_attn", "cross_attn"):
+        for m in ("q", "k", "v", "o"):
+            w[f"blocks.0.{a}.{m}.weight"] = (torch.randn(d, d, generator=g) * d ** -0.5).to(torch.bfloat16)
+            w[f"blocks.0.{a}.{m}.bias"] = torch.zeros(d, dtype=torch.bfloat16)
+        w[f"blocks.0.{a}.norm_q.weight"] = torch.ones(d, dtype=torch.bfloat16)
+        w[f"blocks.0.{a}.norm_k.weight"] = torch.ones(d, dtype=torch.bfloat16)
+    w["blocks.0.norm3.weight"], w["blocks.0.norm3.bias"] = torch.ones(d, dtype=torch.bfloat16), torch.zeros(d, dtype=torch.bfloat16)
+    w["blocks.0.ffn.0.weight"] = (torch.randn(ffn, d, generator=g) * d ** -0.5).to(torch.bfloat16)
+    w["blocks.0.ffn.0.bias"] = torch.zeros(ffn, dtype=torch.bfloat16)
+    w["blocks.0.ffn.2.weight"] = (torch.randn(d, ffn, generator=g) * ffn ** -0.5).to(torch.bfloat16)
+    w["blocks.0.ffn.2.bias"] = torch.zeros(d, dtype=torch.bfloat16)
+    w["blocks.0.modulation"] = (torch.randn(1, 6, d, generator=g) * d ** -0.5).to(torch.bfloat16)
+    x = torch.randn(1, 4680, d, generator=g).to(torch.bfloat16)
+    e = torch.randn(1, 3, 6, d, generator=g).to(torch.bfloat16) * 0.1
+    ctx = torch.randn(1, 512, d, generator=g).to(torch.bfloat16)
+    kv = wo.initialize_kv_cache(1, 1, 9360, H, 128, torch.bfloat16)[0]
+    kv["k"][:, :4680].normal_(generator=g)
+    kv["v"][:, :4680].normal_(generator=g)
+    kv["global_end_index"] = kv["local_end_index"] = 4680
+    ca = wo.initialize_crossattn_cache(1, 1, H, 128, torch.bfloat16)[0]
+    freqs = wo.rope_table(128)
+    t0 = time.time()
+    with torch.inference_mode():
+        wo.attention_block(w, "blocks.0", x, e, (3, 30, 52), freqs, ctx, H, kv, ca, 4680, False)
+    t_layer = time.time() - t0
+    L = model_cfg["num_layers"]
+    t_block = t_layer * L * 4.88
+    return {"value": 12.0 / t_block, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"1 DiT layer at the benchmarked width (d={d}, ffn={ffn}, H={H}), M=4680 query tokens, 9360 cached "
+                      f"keys, bf16 eager oracle, {t_layer:.2f} s measured once; extrapolated x{L} layers x 4.88 forwards "
+                      f"per 12-frame block, DiT only (VAE excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="14b", choices=sorted(MODELS))
+    ap.add_argument("--kv-cache-num-frames", type=int, default=3)
+    ap.add_argument("--denoising-steps", type=int, default=4)
+    ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-tile-cfg", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    from realtime_video_amd import ops
+    from realtime_video_amd.causal_model import CausalWanModel
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
+
+    mc = MODELS[args.model]
+    model = CausalWanModel(dim=mc["dim"], ffn_dim=mc["ffn_dim"], num_heads=mc["num_heads"], num_layers=mc["num_layers"],
+                           text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)
+    model.gemm_tile_cfg = args.gemm_tile_cfg
+    wr = WanDiffusionWrapper(model, timestep_shift=5.0)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
+                                   generator=wr)
+    vae = None if args.no_vae else VAEDecoderWrapper(dev).init_random_weights(seed=1)
+    g = torch.Generator(device=dev).manual_seed(42)
+    prompt = torch.zeros(1, 512, 4096, dtype=torch.bfloat16, device=dev)
+    prompt[:, :64] = torch.randn(1, 64, 4096, generator=g, device=dev).to(torch.bfloat16)
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(prompt), vae_decoder=vae)
+    n_blocks = args.warmup + args.steps
+    params = GenerateParams(prompt="synthetic", seed=42, kv_cache_num_frames=args.kv_cache_num_frames,
+                            num_blocks=n_blocks, num_denoising_steps=args.denoising_steps, keep_first_frame=True)
+    sess = GenerationSession(params, models, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sess.generate_block()
+    barrier()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    t0 = time.perf_counter()
+    frames = 0
+    for _ in range(args.steps):
+        out = sess.generate_block()
+        frames += 12
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.prof_enable(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out.float()).all(), "non-finite output"
+
+    prof = {k: ops.prof_read(k) for k in ("gemm", "attn", "layernorm", "rope", "conv", "misc")}
+    if rank != 0:
+        return
+    total_frames = frames * world  # replicas: every rank generates its own stream
+    gm = prof["gemm"]
+    achieved = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
+    fwd_per_block = args.denoising_steps + 1
+    result = {
+        "metric": "frames/sec at 832x480, 4-step 14B T2V (per-step DiT latency in config)",
+        "value": total_frames / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": (total_frames / elapsed) / 11.0 if args.model == "14b" and world == 1 and not args.no_vae else None,
+        "dtype": "bf16",
+        "data": "synthetic (random-init weights of the named architecture, N(0,1) latents/noise, N(0,1) prompt embeddings)",
+        "config": {
+            "workload": f"{mc['name']}, 832x480 (latent 60x104, 1560 tokens/frame), {args.denoising_steps} denoising steps, "
+                        f"kv_cache_num_frames={args.kv_cache_num_frames}, 3 latent frames (12 pixel frames) per block, "
+                        f"KV-recompute forward every block, streaming VAE decode {'OFF (INVALID: diagnostic run)' if args.no_vae else 'on (fp16)'}",
+            "model": args.model,
+            "keep_first_frame": True,
+            "note": "first-frame VAE re-encode (release_server.py:572-575, 2.72 of 774.5 TFLOP/block) is not built yet: "
+                    "the session runs with keep_first_frame=True",
+            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+            "dit_ms_per_forward": (prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
+                                   + prof["misc"]["ms"]) / (args.steps * fwd_per_block),
+            "vae_ms_per_block": prof["conv"]["ms"] / args.steps,
+            "kernel_ms_per_block": {k: v["ms"] / args.steps for k, v in prof.items()},
+        },
+        "roofline": {
+            "kernel": "gemm_kernel (bf16 MFMA projection GEMM, all DiT linears)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches": gm["launches"],
+            "avg_launch_ms": gm["ms"] / max(gm["launches"], 1),
+            "attention_TFLOPs": prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12 if prof["attn"]["ms"] > 0 else None,
+            "conv_TFLOPs": prof["conv"]["work"] / (prof["conv"]["ms"] * 1e-3) / 1e12 if prof["conv"]["ms"] > 0 else None,
+        },
+    }
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(mc)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -97,7 +97,7 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
     if (e != hipSuccess) return set_error(e, "gemm: hipFuncSetAttribute");
     attr_set = true;
   }
-  ProfScope prof(PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);  // fp16 GEMMs belong to the VAE
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
   return check_launch("gemm");
 }

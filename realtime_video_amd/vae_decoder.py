@@ -156,6 +156,60 @@ class VAEDecoderWrapper:
         self._t, self._w = t, W
         return [], []
 
+    @staticmethod
+    def state_dict_spec():
+        """(name, shape) of every tensor of the reference decoder state_dict (vae_block3.py:334-384 built
+        from wan/modules/vae.py blocks), in module order."""
+        spec = [("conv2.weight", (16, 16, 1, 1, 1)), ("conv2.bias", (16,)),
+                ("decoder.conv1.weight", (384, 16, 3, 3, 3)), ("decoder.conv1.bias", (384,))]
+
+        def res(pre, cin, cout):
+            out = [(pre + ".residual.0.gamma", (cin, 1, 1, 1)), (pre + ".residual.2.weight", (cout, cin, 3, 3, 3)),
+                   (pre + ".residual.2.bias", (cout,)), (pre + ".residual.3.gamma", (cout, 1, 1, 1)),
+                   (pre + ".residual.6.weight", (cout, cout, 3, 3, 3)), (pre + ".residual.6.bias", (cout,))]
+            if cin != cout:
+                out += [(pre + ".shortcut.weight", (cout, cin, 1, 1, 1)), (pre + ".shortcut.bias", (cout,))]
+            return out
+
+        spec += res("decoder.middle.0", 384, 384)
+        spec += [("decoder.middle.1.norm.gamma", (384, 1, 1)), ("decoder.middle.1.to_qkv.weight", (1152, 384, 1, 1)),
+                 ("decoder.middle.1.to_qkv.bias", (1152,)), ("decoder.middle.1.proj.weight", (384, 384, 1, 1)),
+                 ("decoder.middle.1.proj.bias", (384,))]
+        spec += res("decoder.middle.2", 384, 384)
+        li, cin = 0, 384
+        for s, cout in enumerate((384, 384, 192, 96)):
+            if s > 0:
+                cin //= 2
+            for _ in range(3):
+                spec += res(f"decoder.upsamples.{li}", cin, cout)
+                cin = cout
+                li += 1
+            if s != 3:
+                pre = f"decoder.upsamples.{li}"
+                if s < 2:
+                    spec += [(pre + ".time_conv.weight", (2 * cout, cout, 3, 1, 1)), (pre + ".time_conv.bias", (2 * cout,))]
+                spec += [(pre + ".resample.1.weight", (cout // 2, cout, 3, 3)), (pre + ".resample.1.bias", (cout // 2,))]
+                li += 1
+        spec += [("decoder.head.0.gamma", (96, 1, 1, 1)), ("decoder.head.2.weight", (3, 96, 3, 3, 3)),
+                 ("decoder.head.2.bias", (3,))]
+        return spec
+
+    def init_random_weights(self, seed=0):
+        """Synthetic decoder weights generated on the GPU (bench.py / smoke: no Wan2.1_VAE.pth offline):
+        PyTorch-default uniform(-1/sqrt(fan_in), +) convs, gammas near 1."""
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        sd = {}
+        for name, shape in self.state_dict_spec():
+            if name.endswith("gamma"):
+                sd[name] = 1 + 0.1 * torch.randn(shape, generator=g, device=self.device)
+            else:
+                wname = name[:-5] + ".weight" if name.endswith(".bias") else name
+                wshape = dict(self.state_dict_spec())[wname]
+                bound = 1.0 / math.sqrt(math.prod(wshape[1:]))
+                sd[name] = (torch.rand(shape, generator=g, device=self.device) * 2 - 1) * bound
+        self.load_state_dict(sd)
+        return self
+
     # ------------------------------------------------------------------ arena / cache views
     def _new_arena(self, h, w):
         lib = _lib.load()
