@@ -60,23 +60,24 @@ int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o,
  * C[M,N] = epi(A[M,K] @ W[N,K]^T): replaces nn.Linear (causal_model.py:196-199,:246,:433-435,
  * :614-623; model.py:184-198) plus the eager chains bias -> GELU(tanh) (:434), y*e[2]+x (:476),
  * y*e[5]+x (:487-488), x + cross_attn (:480).
- *   bias[N] (nullable); act RTV_ACT_*; gate (nullable): gate[(m / rows_per_frame)*gate_stride + n];
+ *   bias[N] (nullable); act RTV_ACT_*; gate (nullable): gate[((row_offset + m) / rows_per_frame)*gate_stride + n]
+ *   (row_offset = global index of local row 0 when the token axis is sharded across GPUs);
  *   residual[M,ldr] (nullable, may alias C).  tile_cfg 0 = default. */
 int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
              int M, int N, int K,
              const void* bias, int act,
-             const void* gate, int gate_stride, int rows_per_frame,
+             const void* gate, int gate_stride, int rows_per_frame, int row_offset,
              const void* residual, int ldr,
              int dtype, int tile_cfg, rtv_stream_t stream);
 
 /* ---- K5: fused norm / modulation / RoPE / KV-cache write ----------------------------------
- * rtv_layernorm_modulate: out = LN(x; eps, no affine) * (1 + scale[f]) + shift[f], f = m / rows_per_frame
+ * rtv_layernorm_modulate: out = LN(x; eps, no affine) * (1 + scale[f]) + shift[f], f = (row_offset + m) / rows_per_frame
  *   (causal_model.py:471, :483-484, :522; WanLayerNorm model.py:88-98).  shift/scale nullable ->
  *   plain LN; weight/bias (nullable) -> affine LN (norm3, causal_model.py:424-426,:480).
  *   shift and scale point at frame 0's [d] vectors; frame_stride elements between frames. */
 int rtv_layernorm_modulate(const void* x, void* out, int M, int d, float eps,
                            const void* shift, const void* scale, int frame_stride, int rows_per_frame,
-                           const void* weight, const void* bias, rtv_stream_t stream);
+                           int row_offset, const void* weight, const void* bias, rtv_stream_t stream);
 
 /* rtv_rmsnorm: out = bf16(x * rsqrt(mean(x^2)+eps)) * weight over the full channel dim
  *   (WanRMSNorm model.py:69-85; used for cross-attention q/k, model.py:184,:189). */
@@ -88,12 +89,13 @@ int rtv_rmsnorm(const void* x, int ldx, void* out, int ldo, int M, int d, float 
  *   v -> v_cache rows likewise.  Replaces causal_model.py:243-256 (norm), :143-171 / model.py:39-66
  *   (3-axis RoPE; rope_cs is float2 [1024][hd/2] = (cos,sin) of rope_params model.py:28-35 laid out as
  *   causal_model.py:639-645), :380-385 / :309-311 (cache write).  Token m -> (f,h,w) on grid (F,gh,gw),
- *   temporal position start_frame + f.  Cache row stride in elements. */
+ *   temporal position start_frame + f.  Cache row stride in elements.  With a sharded token axis the call
+ *   covers local rows only: M rows starting at global token row_offset (cache rows cache_row0 + row_offset + m). */
 int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_cache,
                            int64_t cache_row_stride, int cache_row0,
                            int M, int d, int num_heads, float eps,
                            const void* wq, const void* wk, const void* rope_cs,
-                           int F, int gh, int gw, int start_frame, rtv_stream_t stream);
+                           int F, int gh, int gw, int start_frame, int row_offset, rtv_stream_t stream);
 
 /* rtv_modulation_table: emod[l][f][j][:] = bf16(modulation[l][j][:] + e0[f][j][:]) for l<L, j<J
  *   (causal_model.py:466, :521).  modulation:[L][J][d], e0:[F][J0][d] with J0 = J or 1 (broadcast). */
@@ -164,11 +166,28 @@ typedef struct rtv_dit_step {
   int start_frame;          /* RoPE temporal offset (current_start // 1560, :351-356; 0 for the recompute pass) */
   int causal_block;         /* 0 = dense; >0 = block-causal recompute pass (tokens per block, :305-348) */
   int gemm_tile_cfg;        /* 0 = default */
+  int row_begin, row_count; /* token rows owned by this rank (context parallel); 0,0 = all M rows */
 } rtv_dit_step;
 
 size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw);
 int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step,
                     void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+
+/* Phase API for token-axis (context-parallel) sharding — the new design for wan/distributed
+ * (xdit_context_parallel.py:131-142 chunk + all_gather pattern, applied to the causal model):
+ *   begin; for each layer { layer_qkv; <host: all-gather cache rows [cache_row0, cache_row0+M) of K and V
+ *   over RCCL>; layer_rest }; head -> head_rows[row_begin..]; <host: all-gather head_rows>; finish.
+ * Every call works on the local rows [row_begin, row_begin+row_count) only; head_rows is a caller-owned
+ * [M][out_dim*4] bf16 buffer. */
+int rtv_dit_begin(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step,
+                  void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+int rtv_dit_layer_qkv(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer,
+                      void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+int rtv_dit_layer_rest(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer,
+                       void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, void* head_rows,
+                 void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+int rtv_dit_finish(const rtv_dit_config* cfg, const rtv_dit_step* step, const void* head_rows, rtv_stream_t stream);
 
 /* ---- K6/K7: streaming VAE decoder ---------------------------------------------------------------
  * fp16, channels-last activations [T][H][W][C].

@@ -27,11 +27,11 @@ SIGNATURES = {
                      c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                      c_f32, c_int, c_int, c_int, c_vp],
     "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
-                 c_vp, c_int, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
-    "rtv_layernorm_modulate": [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_vp],
+                 c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
+    "rtv_layernorm_modulate": [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp],
     "rtv_rmsnorm": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp],
     "rtv_qk_norm_rope_cache": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32,
-                               c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+                               c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "rtv_modulation_table": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "rtv_sinusoidal_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
     "rtv_patchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],

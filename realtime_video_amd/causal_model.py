@@ -51,12 +51,19 @@ class _Step(ctypes.Structure):
                 ("ca_k", ctypes.POINTER(c_vp)), ("ca_v", ctypes.POINTER(c_vp)),
                 ("compute_cross_kv", ctypes.c_int), ("cache_row0", ctypes.c_int),
                 ("kv_lo", ctypes.c_int), ("kv_hi", ctypes.c_int), ("start_frame", ctypes.c_int),
-                ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int)]
+                ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int),
+                ("row_begin", ctypes.c_int), ("row_count", ctypes.c_int)]
 
 
 _lib.EXTRA_SIGNATURES["rtv_dit_forward"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step),
                                             c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_silu"] = [c_vp, c_vp, ctypes.c_int64, c_vp]
+_P3 = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step)]
+_lib.EXTRA_SIGNATURES["rtv_dit_begin"] = _P3 + [c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_layer_qkv"] = _P3 + [ctypes.c_int, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_layer_rest"] = _P3 + [ctypes.c_int, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_head"] = _P3 + [c_vp, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_finish"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Step), c_vp, c_vp]
 
 
 class BlockCausalMask:
@@ -114,6 +121,7 @@ class CausalWanModel:
         self.num_frame_per_block = 1
         self.independent_first_frame = False
         self.gemm_tile_cfg = 0
+        self.context_parallel = None   # realtime_video_amd.parallel.ContextParallel when the token axis is sharded
         self._tensors = {}      # name -> device tensor (keeps the memory alive)
         self._w = None          # ctypes weight table
         self._ws = {}           # (F, gh, gw) -> workspace tensor
@@ -225,8 +233,8 @@ class CausalWanModel:
         return BlockCausalMask(num_frames, frame_seqlen, num_frame_per_block, local_attn_size)
 
     # ------------------------------------------------------------------ forward
-    def _workspace(self, F, gh, gw):
-        key = (F, gh, gw)
+    def _workspace(self, F, gh, gw, slot=0):
+        key = (F, gh, gw, slot)
         ws = self._ws.get(key)
         if ws is None:
             lib = _lib.load()
@@ -305,9 +313,13 @@ class CausalWanModel:
             ctx[:cu.shape[0]] = cu.to(torch.bfloat16)
         row0, lo, hi, start_frame, causal_block = self._cache_window(kv_cache, M, current_start, fs)
         L = self.num_layers
+        rs = kv_cache[0]["k"].stride(1)
         for c in kv_cache:
-            if c["k"].stride(1) != c["k"].stride(2) * c["k"].shape[2] or c["k"].stride(3) != 1:
-                raise ValueError("KV cache tensors must be [B, kv_size, H, 128] with dense [H, 128]")
+            for n in ("k", "v"):
+                if c[n].stride(3) != 1 or c[n].stride(2) != c[n].shape[3] or c[n].stride(1) != rs:
+                    raise ValueError("KV cache tensors must be [B, kv_size, H, 128] views with dense [H, 128] rows "
+                                     "and one common row stride")
+
         def ptr_array(tensors):
             arr = (c_vp * L)(*[t_.data_ptr() for t_ in tensors])
             return arr, ctypes.cast(arr, ctypes.POINTER(c_vp))
@@ -317,14 +329,39 @@ class CausalWanModel:
         ck_keep, ck = ptr_array([c["k"] for c in crossattn_cache])
         cv_keep, cv = ptr_array([c["v"] for c in crossattn_cache])
         out = torch.empty((self.out_dim, F, Hh, Ww), dtype=torch.bfloat16, device=u.device)
-        ws = self._workspace(F, gh, gw)
-        ws_ptr = (ws.data_ptr() + 255) & ~255
-        st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
-                   F, gh, gw, kk, kv, kv_cache[0]["k"].stride(1), ck, cv, int(need_cross), row0, lo, hi,
-                   start_frame, causal_block, int(self.gemm_tile_cfg))
-        _lib.call("rtv_dit_forward", ctypes.byref(self._cfg), ctypes.byref(self._w), ctypes.byref(st),
-                  c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())),
-                  c_vp(torch.cuda.current_stream().cuda_stream))
+        cp = self.context_parallel
+        stream = c_vp(torch.cuda.current_stream().cuda_stream)
+        cfg_p, w_p = ctypes.byref(self._cfg), ctypes.byref(self._w)
+
+        def make(rank_rows, slot):
+            ws = self._workspace(F, gh, gw, slot)
+            ws_ptr = (ws.data_ptr() + 255) & ~255
+            st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
+                       F, gh, gw, kk, kv, rs, ck, cv, int(need_cross), row0, lo, hi,
+                       start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1])
+            return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
+
+        if cp is None or cp.world == 1:
+            st, wsa = make((0, 0), 0)
+            _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)
+        else:
+            # context parallel: local rows only, ONE K/V all-gather per layer (parallel.py).  `local_ranks` is
+            # [rank] in production; a single-process simulation of several ranks runs them in lockstep.
+            from .parallel import shard_rows
+            parts = [make(shard_rows(M, cp.world, r), i) for i, r in enumerate(cp.local_ranks())]
+            for st, wsa in parts:
+                _lib.call("rtv_dit_begin", cfg_p, w_p, ctypes.byref(st), *wsa)
+            for l in range(L):
+                for st, wsa in parts:
+                    _lib.call("rtv_dit_layer_qkv", cfg_p, w_p, ctypes.byref(st), l, *wsa)
+                cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                for st, wsa in parts:
+                    _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
+            hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
+            for st, wsa in parts:
+                _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)
+            cp.all_gather_rows_(hrow)
+            _lib.call("rtv_dit_finish", cfg_p, ctypes.byref(parts[0][0]), c_vp(hrow.data_ptr()), stream)
         if need_cross:
             for c in crossattn_cache:
                 c["is_init"] = True

@@ -1,7 +1,12 @@
-// Whole-forward orchestrator: one call = CausalWanModel._forward_inference
+// DiT forward orchestrator: CausalWanModel._forward_inference
 // (wan/modules/causal_model.py:825-954; block body :440-492; head :495-523; unpatchify :1126-1149).
 // Pure launch sequencing over the kernels of this library on ONE stream: no allocation, no sync, so
-// the call is hipGraph-capturable.  13 launches per DiT layer.
+// every entry is hipGraph-capturable.  13 launches per DiT layer.
+//
+// Token-axis (context-parallel) sharding: a rank owns token rows [row_begin, row_begin + row_count) of the
+// M = F*gh*gw tokens.  Every per-token op runs on the local rows only; the single exchange per layer is the
+// all-gather of the new K/V rows into the replicated KV cache, done by the host (RCCL via torch.distributed)
+// between rtv_dit_layer_qkv and rtv_dit_layer_rest.  rtv_dit_forward = the unsharded composition.
 #include "rtv_common.h"
 #include "rtv_internal.h"
 
@@ -29,6 +34,7 @@ struct DitBuffers {
   uint16_t *sinus, *te1, *e, *se, *e0, *emod, *ehead, *ctx1, *ctx, *ktmp;
 };
 
+// Buffers are sized for the full token count so that one workspace serves sharded and unsharded calls.
 static size_t carve(const rtv_dit_config* c, int F, int gh, int gw, char* base, size_t cap, DitBuffers* b,
                     bool* ok) {
   Workspace ws{base, 0, cap, true};
@@ -57,6 +63,48 @@ static size_t carve(const rtv_dit_config* c, int F, int gh, int gw, char* base, 
   return ws.off;
 }
 
+struct Ctx {
+  const rtv_dit_config* cfg;
+  const rtv_dit_weights* w;
+  const rtv_dit_step* st;
+  DitBuffers b;
+  rtv_stream_t stream;
+  int d, H, L, ffn, hd, F, gh, gw, fs, M, r0, rc, tc;
+};
+
+static int make_ctx(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, void* workspace,
+                    size_t workspace_bytes, rtv_stream_t stream, Ctx* c) {
+  if (!cfg || !w || !st || !workspace) return set_error(-1, "dit: null argument");
+  c->cfg = cfg;
+  c->w = w;
+  c->st = st;
+  c->stream = stream;
+  c->d = cfg->dim;
+  c->H = cfg->num_heads;
+  c->L = cfg->num_layers;
+  c->ffn = cfg->ffn_dim;
+  if (c->H <= 0 || c->d % c->H || c->d / c->H != 128) return set_error(-1, "dit: head_dim must be 128");
+  c->hd = 128;
+  c->F = st->F;
+  c->gh = st->gh;
+  c->gw = st->gw;
+  c->fs = st->gh * st->gw;
+  c->M = st->F * c->fs;
+  if (c->M <= 0) return set_error(-1, "dit: empty token grid");
+  c->r0 = st->row_begin;
+  c->rc = st->row_count > 0 ? st->row_count : c->M - st->row_begin;
+  if (c->r0 < 0 || c->rc <= 0 || c->r0 + c->rc > c->M) return set_error(-1, "dit: local row range outside the token grid");
+  if (st->kv_lo < 0 || st->kv_hi <= st->kv_lo) return set_error(-1, "dit: empty attention window");
+  if (st->cache_row0 < 0 || st->cache_row0 + c->M > st->kv_hi)
+    return set_error(-1, "dit: the rows written by this call must lie inside the attention window");
+  if (((uintptr_t)workspace) & 255) return set_error(-1, "dit: workspace must be 256-byte aligned");
+  bool ok = true;
+  carve(cfg, c->F, c->gh, c->gw, (char*)workspace, workspace_bytes, &c->b, &ok);
+  if (!ok) return set_error(-1, "dit: workspace too small (see rtv_dit_workspace_bytes)");
+  c->tc = st->gemm_tile_cfg;
+  return 0;
+}
+
 }  // namespace rtv
 
 using namespace rtv;
@@ -81,91 +129,153 @@ extern "C" size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int 
   return carve(cfg, F, gh, gw, nullptr, 0, nullptr, nullptr) + 256;
 }
 
+// nn.Linear on `M` rows with optional fused epilogue; `row_off` = global index of row 0 for the per-frame gate.
 static int linear(const void* a, int K, const void* w, const void* bias, void* out, int M, int N, int act,
-                  const void* gate, int gate_stride, int rpf, const void* res, int cfg, rtv_stream_t s) {
-  return rtv_gemm(a, K, w, K, out, N, M, N, K, bias, act, gate, gate_stride, rpf, res, N, RTV_DTYPE_BF16, cfg, s);
+                  const void* gate, int gate_stride, int rpf, int row_off, const void* res, int cfg, rtv_stream_t s) {
+  return rtv_gemm(a, K, w, K, out, N, M, N, K, bias, act, gate, gate_stride, rpf, row_off, res, N, RTV_DTYPE_BF16, cfg, s);
+}
+
+// ---- embeddings, modulation tables, cross-attention K/V (causal_model.py:874-902)
+static int dit_begin(Ctx& c) {
+  const rtv_dit_config* cfg = c.cfg;
+  const rtv_dit_weights* w = c.w;
+  const rtv_dit_step* st = c.st;
+  DitBuffers& b = c.b;
+  const int d = c.d, F = c.F, L = c.L, tc = c.tc;
+  rtv_stream_t stream = c.stream;
+  const int pk = cfg->in_dim * 4;
+  RTV_TRY(rtv_patchify(st->x, b.prow, cfg->in_dim, F, c.gh, c.gw, stream));
+  RTV_TRY(linear(b.prow + (size_t)c.r0 * pk, pk, w->patch_w, w->patch_b, b.x, c.rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_sinusoidal_embedding(st->t, b.sinus, F, cfg->freq_dim, stream));
+  RTV_TRY(linear(b.sinus, cfg->freq_dim, w->time0_w, w->time0_b, b.te1, F, d, RTV_ACT_SILU, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(b.te1, d, w->time2_w, w->time2_b, b.e, F, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_silu(b.e, b.se, (int64_t)F * d, stream));
+  RTV_TRY(linear(b.se, d, w->tproj_w, w->tproj_b, b.e0, F, 6 * d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_modulation_table(w->modulation, b.e0, b.emod, L, F, 6, 6, d, stream));
+  RTV_TRY(rtv_modulation_table(w->head_modulation, b.e, b.ehead, 1, F, 2, 1, d, stream));
+  // text context -> cross-attention K/V caches, only while they are not initialised (model.py:186-192;
+  // the text MLP output is consumed nowhere else, causal_model.py:897-902).  Replicated on every rank.
+  if (st->compute_cross_kv) {
+    if (!st->context) return set_error(-1, "dit: context required to initialise the cross-attention cache");
+    const int T = cfg->text_len;
+    RTV_TRY(linear(st->context, cfg->text_dim, w->text0_w, w->text0_b, b.ctx1, T, d, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
+    RTV_TRY(linear(b.ctx1, d, w->text2_w, w->text2_b, b.ctx, T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+    for (int l = 0; l < L; ++l) {
+      const rtv_dit_layer_weights& lw = w->layers[l];
+      RTV_TRY(linear(b.ctx, d, lw.ck_w, lw.ck_b, b.ktmp, T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+      RTV_TRY(rtv_rmsnorm(b.ktmp, d, st->ca_k[l], d, T, d, cfg->eps, lw.cnorm_k_w, stream));
+      RTV_TRY(linear(b.ctx, d, lw.cv_w, lw.cv_b, st->ca_v[l], T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+    }
+  }
+  return 0;
+}
+
+// ---- layer, part 1: LN+modulate -> QKV -> RMSNorm(q,k)+RoPE -> local K/V rows into the cache
+static int dit_layer_qkv(Ctx& c, int l) {
+  const rtv_dit_layer_weights& lw = c.w->layers[l];
+  const rtv_dit_step* st = c.st;
+  DitBuffers& b = c.b;
+  const int d = c.d;
+  const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;  // [F][6][d]: shift_sa, scale_sa, gate_sa, shift_ffn, scale_ffn, gate_ffn
+  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
+  RTV_TRY(linear(b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
+  RTV_TRY(rtv_qk_norm_rope_cache(b.qkv, b.q, st->kv_k[l], st->kv_v[l], st->kv_row_stride, st->cache_row0, c.rc, d, c.H,
+                                 c.cfg->eps, lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame,
+                                 c.r0, c.stream));
+  return 0;
+}
+
+// ---- layer, part 2: attention over the cache window -> o-proj(+gate,+res) -> cross-attn -> FFN
+static int dit_layer_rest(Ctx& c, int l) {
+  const rtv_dit_layer_weights& lw = c.w->layers[l];
+  const rtv_dit_step* st = c.st;
+  DitBuffers& b = c.b;
+  const int d = c.d, H = c.H, hd = c.hd, fs = c.fs, tc = c.tc, rc = c.rc, r0 = c.r0;
+  rtv_stream_t stream = c.stream;
+  const float eps = c.cfg->eps;
+  const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;
+  const float scale = 1.0f / sqrtf((float)hd);
+  const int64_t rs = st->kv_row_stride;
+  const int Lkv = st->kv_hi - st->kv_lo;
+  const int q_offset = st->cache_row0 - st->kv_lo + r0;  // position of local query row 0 inside the window
+  uint16_t* kc = (uint16_t*)st->kv_k[l];
+  uint16_t* vc = (uint16_t*)st->kv_v[l];
+  // self attention (causal_model.py:386-390, :470-476)
+  RTV_TRY(rtv_attn_fwd(b.q, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, b.ao, 1, rc, Lkv, H, hd,
+                       0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block, st->causal_block > 0 ? q_offset : 0,
+                       RTV_DTYPE_BF16, stream));
+  RTV_TRY(linear(b.ao, d, lw.o_w, lw.o_b, b.x, rc, d, 0, em + 2 * d, 6 * d, fs, r0, b.x, tc, stream));
+  // cross attention (causal_model.py:480, model.py:171-228)
+  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, nullptr, nullptr, 0, 0, 0, lw.norm3_w, lw.norm3_b, stream));
+  RTV_TRY(linear(b.xn, d, lw.cq_w, lw.cq_b, b.qkv, rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(rtv_rmsnorm(b.qkv, d, b.q, d, rc, d, eps, lw.cnorm_q_w, stream));
+  RTV_TRY(rtv_attn_fwd(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, rc, c.cfg->text_len, H, hd, 0, d, 0, d, 0, d, 0, d,
+                       scale, 0, 0, RTV_DTYPE_BF16, stream));
+  RTV_TRY(linear(b.ao, d, lw.co_w, lw.co_b, b.x, rc, d, 0, nullptr, 0, 0, 0, b.x, tc, stream));
+  // FFN (causal_model.py:482-488)
+  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, em + 3 * d, em + 4 * d, 6 * d, fs, r0, nullptr, nullptr, stream));
+  RTV_TRY(linear(b.xn, d, lw.ffn0_w, lw.ffn0_b, b.h, rc, c.ffn, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(b.h, c.ffn, lw.ffn2_w, lw.ffn2_b, b.x, rc, d, 0, em + 5 * d, 6 * d, fs, r0, b.x, tc, stream));
+  return 0;
+}
+
+// ---- head on local rows (causal_model.py:512-523) -> head_rows[row_begin : row_begin+row_count)
+static int dit_head(Ctx& c, void* head_rows) {
+  DitBuffers& b = c.b;
+  const int d = c.d, n = c.cfg->out_dim * 4;
+  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, b.ehead + 0 * d, b.ehead + 1 * d, 2 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
+  RTV_TRY(linear(b.xn, d, c.w->head_w, c.w->head_b, (uint16_t*)head_rows + (size_t)c.r0 * n, c.rc, n, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
+  return 0;
+}
+
+extern "C" int rtv_dit_begin(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, void* ws,
+                             size_t ws_bytes, rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  return dit_begin(c);
+}
+
+extern "C" int rtv_dit_layer_qkv(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,
+                                 void* ws, size_t ws_bytes, rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
+  return dit_layer_qkv(c, layer);
+}
+
+extern "C" int rtv_dit_layer_rest(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,
+                                  void* ws, size_t ws_bytes, rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
+  return dit_layer_rest(c, layer);
+}
+
+extern "C" int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, void* head_rows,
+                            void* ws, size_t ws_bytes, rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (!head_rows) return set_error(-1, "dit: head_rows required");
+  return dit_head(c, head_rows);
+}
+
+extern "C" int rtv_dit_finish(const rtv_dit_config* cfg, const rtv_dit_step* st, const void* head_rows,
+                              rtv_stream_t stream) {
+  if (!cfg || !st || !head_rows || !st->out) return set_error(-1, "dit: null argument");
+  return rtv_unpatchify(head_rows, st->out, cfg->out_dim, st->F, st->gh, st->gw, stream);
 }
 
 extern "C" int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st,
                                void* workspace, size_t workspace_bytes, rtv_stream_t stream) {
-  if (!cfg || !w || !st || !workspace) return set_error(-1, "dit_forward: null argument");
-  const int d = cfg->dim, H = cfg->num_heads, L = cfg->num_layers, ffn = cfg->ffn_dim;
-  if (H <= 0 || d % H || d / H != 128) return set_error(-1, "dit_forward: head_dim must be 128");
-  const int F = st->F, gh = st->gh, gw = st->gw;
-  const int fs = gh * gw, M = F * fs;
-  if (M <= 0) return set_error(-1, "dit_forward: empty token grid");
-  if (st->kv_lo < 0 || st->kv_hi <= st->kv_lo) return set_error(-1, "dit_forward: empty attention window");
-  if (st->cache_row0 < 0 || st->cache_row0 + M > st->kv_hi)
-    return set_error(-1, "dit_forward: the rows written by this call must lie inside the attention window");
-  if (((uintptr_t)workspace) & 255) return set_error(-1, "dit_forward: workspace must be 256-byte aligned");
-  DitBuffers b;
-  bool ok = true;
-  carve(cfg, F, gh, gw, (char*)workspace, workspace_bytes, &b, &ok);
-  if (!ok) return set_error(-1, "dit_forward: workspace too small (see rtv_dit_workspace_bytes)");
-  const int tc = st->gemm_tile_cfg;
-  const int hd = d / H;
-
-  // ---- embeddings (causal_model.py:874-902)
-  RTV_TRY(rtv_patchify(st->x, b.prow, cfg->in_dim, F, gh, gw, stream));
-  RTV_TRY(linear(b.prow, cfg->in_dim * 4, w->patch_w, w->patch_b, b.x, M, d, 0, nullptr, 0, 0, nullptr, tc, stream));
-  RTV_TRY(rtv_sinusoidal_embedding(st->t, b.sinus, F, cfg->freq_dim, stream));
-  RTV_TRY(linear(b.sinus, cfg->freq_dim, w->time0_w, w->time0_b, b.te1, F, d, RTV_ACT_SILU, nullptr, 0, 0, nullptr, tc, stream));
-  RTV_TRY(linear(b.te1, d, w->time2_w, w->time2_b, b.e, F, d, 0, nullptr, 0, 0, nullptr, tc, stream));
-  RTV_TRY(rtv_silu(b.e, b.se, (int64_t)F * d, stream));
-  RTV_TRY(linear(b.se, d, w->tproj_w, w->tproj_b, b.e0, F, 6 * d, 0, nullptr, 0, 0, nullptr, tc, stream));
-  RTV_TRY(rtv_modulation_table(w->modulation, b.e0, b.emod, L, F, 6, 6, d, stream));
-  RTV_TRY(rtv_modulation_table(w->head_modulation, b.e, b.ehead, 1, F, 2, 1, d, stream));
-
-  // ---- text context -> cross-attention K/V caches, only while they are not initialised
-  //      (model.py:186-192; the text MLP output is consumed nowhere else, causal_model.py:897-902)
-  if (st->compute_cross_kv) {
-    if (!st->context) return set_error(-1, "dit_forward: context required to initialise the cross-attention cache");
-    const int T = cfg->text_len;
-    RTV_TRY(linear(st->context, cfg->text_dim, w->text0_w, w->text0_b, b.ctx1, T, d, RTV_ACT_GELU_TANH, nullptr, 0, 0, nullptr, tc, stream));
-    RTV_TRY(linear(b.ctx1, d, w->text2_w, w->text2_b, b.ctx, T, d, 0, nullptr, 0, 0, nullptr, tc, stream));
-    for (int l = 0; l < L; ++l) {
-      const rtv_dit_layer_weights& lw = w->layers[l];
-      RTV_TRY(linear(b.ctx, d, lw.ck_w, lw.ck_b, b.ktmp, T, d, 0, nullptr, 0, 0, nullptr, tc, stream));
-      RTV_TRY(rtv_rmsnorm(b.ktmp, d, st->ca_k[l], d, T, d, cfg->eps, lw.cnorm_k_w, stream));
-      RTV_TRY(linear(b.ctx, d, lw.cv_w, lw.cv_b, st->ca_v[l], T, d, 0, nullptr, 0, 0, nullptr, tc, stream));
-    }
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, workspace, workspace_bytes, stream, &c));
+  if (c.r0 != 0 || c.rc != c.M)
+    return set_error(-1, "dit_forward: sharded row ranges need the phase API (rtv_dit_begin/layer_qkv/layer_rest/head/finish)");
+  RTV_TRY(dit_begin(c));
+  for (int l = 0; l < c.L; ++l) {
+    RTV_TRY(dit_layer_qkv(c, l));
+    RTV_TRY(dit_layer_rest(c, l));
   }
-
-  const float scale = 1.0f / sqrtf((float)hd);
-  const int64_t rs = st->kv_row_stride;
-  const int Lkv = st->kv_hi - st->kv_lo;
-  const int q_offset = st->cache_row0 - st->kv_lo;  // position of query row 0 inside the window
-
-  for (int l = 0; l < L; ++l) {
-    const rtv_dit_layer_weights& lw = w->layers[l];
-    const uint16_t* em = b.emod + (size_t)l * F * 6 * d;  // [F][6][d]: shift_sa, scale_sa, gate_sa, shift_ffn, scale_ffn, gate_ffn
-    uint16_t* kc = (uint16_t*)st->kv_k[l];
-    uint16_t* vc = (uint16_t*)st->kv_v[l];
-    // -- self attention (causal_model.py:470-476)
-    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, em + 0 * d, em + 1 * d, 6 * d, fs, nullptr, nullptr, stream));
-    RTV_TRY(linear(b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, M, 3 * d, 0, nullptr, 0, 0, nullptr, tc, stream));
-    RTV_TRY(rtv_qk_norm_rope_cache(b.qkv, b.q, kc, vc, rs, st->cache_row0, M, d, H, cfg->eps, lw.norm_q_w,
-                                   lw.norm_k_w, w->rope_cs, F, gh, gw, st->start_frame, stream));
-    RTV_TRY(rtv_attn_fwd(b.q, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, b.ao, 1, M, Lkv, H, hd,
-                         0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block, st->causal_block > 0 ? q_offset : 0,
-                         RTV_DTYPE_BF16, stream));
-    RTV_TRY(linear(b.ao, d, lw.o_w, lw.o_b, b.x, M, d, 0, em + 2 * d, 6 * d, fs, b.x, tc, stream));
-    // -- cross attention (causal_model.py:480, model.py:171-228)
-    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, nullptr, nullptr, 0, 0, lw.norm3_w, lw.norm3_b, stream));
-    RTV_TRY(linear(b.xn, d, lw.cq_w, lw.cq_b, b.qkv, M, d, 0, nullptr, 0, 0, nullptr, tc, stream));
-    RTV_TRY(rtv_rmsnorm(b.qkv, d, b.q, d, M, d, cfg->eps, lw.cnorm_q_w, stream));
-    RTV_TRY(rtv_attn_fwd(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, M, cfg->text_len, H, hd, 0, d, 0, d, 0, d, 0, d,
-                         scale, 0, 0, RTV_DTYPE_BF16, stream));
-    RTV_TRY(linear(b.ao, d, lw.co_w, lw.co_b, b.x, M, d, 0, nullptr, 0, 0, b.x, tc, stream));
-    // -- FFN (causal_model.py:482-488)
-    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, em + 3 * d, em + 4 * d, 6 * d, fs, nullptr, nullptr, stream));
-    RTV_TRY(linear(b.xn, d, lw.ffn0_w, lw.ffn0_b, b.h, M, ffn, RTV_ACT_GELU_TANH, nullptr, 0, 0, nullptr, tc, stream));
-    RTV_TRY(linear(b.h, ffn, lw.ffn2_w, lw.ffn2_b, b.x, M, d, 0, em + 5 * d, 6 * d, fs, b.x, tc, stream));
-  }
-
-  // ---- head + unpatchify (causal_model.py:512-523, :1126-1149)
-  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, M, d, cfg->eps, b.ehead + 0 * d, b.ehead + 1 * d, 2 * d, fs, nullptr, nullptr, stream));
-  RTV_TRY(linear(b.xn, d, w->head_w, w->head_b, b.hrow, M, cfg->out_dim * 4, 0, nullptr, 0, 0, nullptr, tc, stream));
-  RTV_TRY(rtv_unpatchify(b.hrow, st->out, cfg->out_dim, F, gh, gw, stream));
-  return 0;
+  RTV_TRY(dit_head(c, c.b.hrow));
+  return rtv_unpatchify(c.b.hrow, st->out, cfg->out_dim, c.F, c.gh, c.gw, stream);
 }

@@ -36,7 +36,7 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
 __global__ __launch_bounds__(EW_THREADS) void layernorm_modulate_kernel(
     const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int d, float eps,
     const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale, int frame_stride,
-    int rows_per_frame, const bf16_t* __restrict__ weight, const bf16_t* __restrict__ bias) {
+    int rows_per_frame, int row_offset, const bf16_t* __restrict__ weight, const bf16_t* __restrict__ bias) {
   __shared__ float red[8];
   const int row = blockIdx.x;
   const int nchunks = d >> 3;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(EW_THREADS) void layernorm_modulate_kernel(
   }
   const float var = block_sum(s2, red) / (float)d;
   const float rstd = rsqrtf(var + eps);
-  const int f = rows_per_frame > 0 ? row / rows_per_frame : 0;
+  const int f = rows_per_frame > 0 ? (row_offset + row) / rows_per_frame : 0;
   const bf16_t* sh = shift ? shift + (size_t)f * frame_stride : nullptr;
   const bf16_t* sc = scale ? scale + (size_t)f * frame_stride : nullptr;
   bf16_t* orow = out + (size_t)row * d;
@@ -152,7 +152,7 @@ struct RopeArgs {
   const bf16_t* wq;
   const bf16_t* wk;
   const float2* rope_cs;  // [1024][hd/2]
-  int gh, gw, start_frame;
+  int gh, gw, start_frame, row_offset;
 };
 
 __device__ __forceinline__ void rope8(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
@@ -202,14 +202,15 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
   const int half = a.hd >> 1;
   const int c1 = half / 3, c0 = half - 2 * c1;
   const int per_frame = a.gh * a.gw;
-  const int f = row / per_frame;
-  const int rem = row - f * per_frame;
+  const int grow = a.row_offset + row;  // global token index
+  const int f = grow / per_frame;
+  const int rem = grow - f * per_frame;
   const int pos_h = rem / a.gw, pos_w = rem - pos_h * a.gw;
   const int pos_f = a.start_frame + f;
 
   bf16_t* qo = a.q_out + (size_t)row * d;
-  bf16_t* ko = a.k_cache + (size_t)(a.cache_row0 + row) * a.cache_row_stride;
-  bf16_t* vo = a.v_cache + (size_t)(a.cache_row0 + row) * a.cache_row_stride;
+  bf16_t* ko = a.k_cache + (size_t)(a.cache_row0 + grow) * a.cache_row_stride;
+  bf16_t* vo = a.v_cache + (size_t)(a.cache_row0 + grow) * a.cache_row_stride;
 #pragma unroll
   for (int i = 0; i < EW_MAXC; ++i) {
     int c = threadIdx.x + i * EW_THREADS;
@@ -305,8 +306,8 @@ using namespace rtv;
 extern "C" {
 
 int rtv_layernorm_modulate(const void* x, void* out, int M, int d, float eps, const void* shift,
-                           const void* scale, int frame_stride, int rows_per_frame, const void* weight,
-                           const void* bias, rtv_stream_t stream) {
+                           const void* scale, int frame_stride, int rows_per_frame, int row_offset,
+                           const void* weight, const void* bias, rtv_stream_t stream) {
   if (M <= 0) return 0;
   if (d % 8 || d > EW_THREADS * 8 * EW_MAXC) return set_error(-1, "layernorm_modulate: d must be a multiple of 8 and <= 8192");
   if ((shift == nullptr) != (scale == nullptr)) return set_error(-1, "layernorm_modulate: shift and scale go together");
@@ -316,7 +317,7 @@ int rtv_layernorm_modulate(const void* x, void* out, int M, int d, float eps, co
   ProfScope prof(PROF_LN, (hipStream_t)stream, 2.0 * M * d * 2);
   hipLaunchKernelGGL(layernorm_modulate_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (bf16_t*)out, d, eps, (const bf16_t*)shift, (const bf16_t*)scale,
-                     frame_stride, rows_per_frame, (const bf16_t*)weight, (const bf16_t*)bias);
+                     frame_stride, rows_per_frame, row_offset, (const bf16_t*)weight, (const bf16_t*)bias);
   return check_launch("layernorm_modulate");
 }
 
@@ -335,13 +336,13 @@ int rtv_rmsnorm(const void* x, int ldx, void* out, int ldo, int M, int d, float 
 int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_cache,
                            int64_t cache_row_stride, int cache_row0, int M, int d, int num_heads, float eps,
                            const void* wq, const void* wk, const void* rope_cs, int F, int gh, int gw,
-                           int start_frame, rtv_stream_t stream) {
+                           int start_frame, int row_offset, rtv_stream_t stream) {
   if (M <= 0) return 0;
   if (num_heads <= 0 || d % num_heads) return set_error(-1, "qk_norm_rope_cache: d % num_heads != 0");
   const int hd = d / num_heads;
   if (d % 8 || d > EW_THREADS * 8 * EW_MAXC || hd % 8 || cache_row_stride % 8)
     return set_error(-1, "qk_norm_rope_cache: alignment (d, head_dim, cache stride multiples of 8; d <= 8192)");
-  if (M != F * gh * gw) return set_error(-1, "qk_norm_rope_cache: M != F*gh*gw");
+  if (row_offset < 0 || row_offset + M > F * gh * gw) return set_error(-1, "qk_norm_rope_cache: rows outside the F*gh*gw token grid");
   if (start_frame < 0 || start_frame + F > 1024 || gh > 1024 || gw > 1024)
     return set_error(-1, "qk_norm_rope_cache: position exceeds the 1024-entry RoPE table");
   if (cache_row0 < 0) return set_error(-1, "qk_norm_rope_cache: negative cache row");
@@ -361,6 +362,7 @@ int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_
   a.gh = gh;
   a.gw = gw;
   a.start_frame = start_frame;
+  a.row_offset = row_offset;
   ProfScope prof(PROF_ROPE, (hipStream_t)stream, 6.0 * M * d * 2);
   hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
   return check_launch("qk_norm_rope_cache");

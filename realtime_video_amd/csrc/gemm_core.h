@@ -27,6 +27,7 @@ struct GemmParams {
   const uint16_t* gate;      // per-frame gate rows or null: gate[(m / rows_per_frame) * gate_stride + n]
   int gate_stride;
   int rows_per_frame;
+  int row_offset;            // global index of row 0 (token-axis sharding)
   const uint16_t* residual;  // [M][ldr] or null (may alias C)
   int ldr;
   int tiles_m, tiles_n;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int m, int n,
     for (int i = 0; i < 4; ++i) v[i] = T::round(silu(v[i]));
   }
   if (p.gate) {
-    const uint16_t* gp = p.gate + (size_t)(m / p.rows_per_frame) * p.gate_stride + n;
+    const uint16_t* gp = p.gate + (size_t)((p.row_offset + m) / p.rows_per_frame) * p.gate_stride + n;
     u32x2 g = *(const u32x2*)gp;
     v[0] = T::round(v[0] * T::to_f32(g[0] & 0xffff));
     v[1] = T::round(v[1] * T::to_f32(g[0] >> 16));

@@ -112,7 +112,7 @@ int rtv_prof_read(int cls, double* total_ms, int64_t* launches, double* total_wo
 }
 
 int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
-             const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame,
+             const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame, int row_offset,
              const void* residual, int ldr, int dtype, int tile_cfg, rtv_stream_t stream) {
   if (!A || !W || !C) return set_error(-1, "gemm: null operand");
   if (((uintptr_t)A | (uintptr_t)W) & 15) return set_error(-1, "gemm: A/W must be 16-byte aligned");
@@ -135,6 +135,7 @@ int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, i
   p.gate = (const uint16_t*)gate;
   p.gate_stride = gate_stride;
   p.rows_per_frame = rows_per_frame;
+  p.row_offset = row_offset;
   p.residual = (const uint16_t*)residual;
   p.ldr = ldr;
   p.tiles_m = p.tiles_n = 0;

@@ -360,7 +360,7 @@ static int res_block(Ctx& c, int ci, int T, int H, int W, int cin, int cout, con
   RTV_TRY(rtv_rmsnorm_silu_cl(tmp, c.cat(ci + 1) + 2 * sl_out, rw.gamma3, cout, npix, 1, c.stream));
   const uint16_t* hres = x;
   if (rw.shortcut.w) {  // 1x1x1 conv = plain GEMM over pixels
-    RTV_TRY(rtv_gemm(x, cin, rw.shortcut.w, cin, sc_buf, cout, (int)npix, cout, cin, rw.shortcut.b, 0, nullptr, 0, 0,
+    RTV_TRY(rtv_gemm(x, cin, rw.shortcut.w, cin, sc_buf, cout, (int)npix, cout, cin, rw.shortcut.b, 0, nullptr, 0, 0, 0,
                      nullptr, 0, RTV_DTYPE_F16, 0, c.stream));
     hres = sc_buf;
   }
@@ -378,7 +378,7 @@ static int mid_attention(Ctx& c, const uint16_t* x, uint16_t* y) {
            *xn = (uint16_t*)(A + c.L->xn_off);
   auto G = [&](const void* a_, int lda, const void* w_, int ldw, void* out, int ldc, int M, int N, int K,
                const void* bias, const void* res, int ldr) {
-    return rtv_gemm(a_, lda, w_, ldw, out, ldc, M, N, K, bias, 0, nullptr, 0, 0, res, ldr, RTV_DTYPE_F16, 0, c.stream);
+    return rtv_gemm(a_, lda, w_, ldw, out, ldc, M, N, K, bias, 0, nullptr, 0, 0, 0, res, ldr, RTV_DTYPE_F16, 0, c.stream);
   };
   RTV_TRY(rtv_rmsnorm_silu_cl(x, xn, a.gamma, C, P, 0, c.stream));
   RTV_TRY(G(xn, C, a.wq, C, q, C, P, C, C, a.bq, nullptr, 0));      // wq/bq carry the 1/sqrt(C) softmax scale

@@ -79,7 +79,7 @@ def attn_fwd(q, k, v, out=None, scale=None, causal_block=0, q_offset=0):
 
 # --------------------------------------------------------------------------------------- GEMM
 def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame=0, residual=None,
-         out=None, tile_cfg=0):
+         out=None, tile_cfg=0, row_offset=0):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T) — nn.Linear with fused bias/activation/gate/residual."""
     _gpu(a, w, bias, gate, residual, out)
     if a.dim() != 2 or w.dim() != 2 or a.shape[1] != w.shape[1]:
@@ -91,7 +91,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
     _lib.call("rtv_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K,
-              _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame),
+              _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame), int(row_offset),
               _ptr(residual), residual.stride(0) if residual is not None else 0,
               _dt(a), int(tile_cfg), _stream())
     return out
@@ -99,14 +99,14 @@ def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame
 
 # --------------------------------------------------------------------------------------- norms
 def layernorm_modulate(x, eps=1e-6, shift=None, scale=None, frame_stride=0, rows_per_frame=0,
-                       weight=None, bias=None, out=None):
+                       weight=None, bias=None, out=None, row_offset=0):
     """LN(x) [* (1+scale[f]) + shift[f]]  or affine LN.  x:[M,d] bf16."""
     _gpu(x, shift, scale, weight, bias)
     M, d = x.shape
     if out is None:
         out = torch.empty_like(x)
     _lib.call("rtv_layernorm_modulate", _ptr(x), _ptr(out), M, d, float(eps), _ptr(shift), _ptr(scale),
-              int(frame_stride), int(rows_per_frame), _ptr(weight), _ptr(bias), _stream())
+              int(frame_stride), int(rows_per_frame), int(row_offset), _ptr(weight), _ptr(bias), _stream())
     return out
 
 
@@ -121,7 +121,7 @@ def rmsnorm(x, weight, eps=1e-6, out=None):
 
 
 def qk_norm_rope_cache(qkv, k_cache, v_cache, cache_row0, num_heads, wq, wk, rope_cs, grid, start_frame,
-                       eps=1e-6, q_out=None):
+                       eps=1e-6, q_out=None, row_offset=0):
     """qkv:[M,3d]; k_cache/v_cache:[kv_size,H,hd] views (row stride = stride(0)); grid=(F,gh,gw)."""
     _gpu(qkv, k_cache, v_cache, wq, wk, rope_cs)
     M, d3 = qkv.shape
@@ -129,11 +129,11 @@ def qk_norm_rope_cache(qkv, k_cache, v_cache, cache_row0, num_heads, wq, wk, rop
     F, gh, gw = grid
     if q_out is None:
         q_out = torch.empty((M, d), dtype=qkv.dtype, device=qkv.device)
-    if cache_row0 + M > k_cache.shape[0]:
+    if cache_row0 + row_offset + M > k_cache.shape[0]:
         raise ValueError("KV-cache write out of range")
     _lib.call("rtv_qk_norm_rope_cache", _ptr(qkv), _ptr(q_out), _ptr(k_cache), _ptr(v_cache),
               k_cache.stride(0), int(cache_row0), M, d, int(num_heads), float(eps), _ptr(wq), _ptr(wk),
-              _ptr(rope_cs), int(F), int(gh), int(gw), int(start_frame), _stream())
+              _ptr(rope_cs), int(F), int(gh), int(gw), int(start_frame), int(row_offset), _stream())
     return q_out
 
 

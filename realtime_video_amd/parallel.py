@@ -1,0 +1,91 @@
+"""Context (sequence) parallelism for the causal DiT forward — one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference only has sequence parallelism for the NON-causal model (xfuser USP monkey-patch,
+wan/distributed/xdit_context_parallel.py:131-142,:179-184); this is the new design for the causal path
+(SURVEY.md §8e): the token axis of every forward is cut into `world` contiguous shards, all per-token
+work (LayerNorm/modulation, every GEMM, RMSNorm, RoPE, cross-attention against the replicated text K/V,
+FFN, head) runs on the local shard only, and the single exchange per layer is an in-place all-gather of
+the new block's roped K and V rows into the (replicated) KV cache; queries then attend the full window
+locally.  One more all-gather returns the head output rows.  xGMI is point-to-point, so the per-layer
+message is deliberately one contiguous buffer per rank (K and V rows interleaved in the cache arena).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(M, world, rank):
+    """Contiguous token shard of rank `rank`: (row_begin, row_count).  M must divide evenly (4680 = 8*585)."""
+    if M % world:
+        raise ValueError(f"token count {M} is not divisible by the context-parallel degree {world}")
+    n = M // world
+    return rank * n, n
+
+
+class ContextParallel:
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self._gloo = dist.get_backend(group) == "gloo"
+
+    def shard(self, M):
+        return shard_rows(M, self.world, self.rank)
+
+    def local_ranks(self):
+        return [self.rank]
+
+    def all_gather_rows_(self, buf):
+        """In-place all-gather along dim 0 of a contiguous buffer whose local shard is already filled."""
+        if self.world == 1:
+            return buf
+        if not buf.is_contiguous() or buf.shape[0] % self.world:
+            raise ValueError("all_gather_rows_ needs a contiguous buffer with rows divisible by the world size")
+        n = buf.shape[0] // self.world
+        mine = buf[self.rank * n:(self.rank + 1) * n]
+        if self._gloo:
+            dist.all_gather([buf[r * n:(r + 1) * n] for r in range(self.world)], mine.clone(), group=self.group)
+        else:
+            dist.all_gather_into_tensor(buf, mine, group=self.group)
+        return buf
+
+    def gather_kv(self, k, v, row0, M):
+        """All-gather cache rows [row0, row0+M) of one layer's K and V ([kv_size, H, hd] views).  If K and V rows
+        are interleaved in one arena ([kv_size, 2, H, hd]) this is ONE collective, otherwise two."""
+        if self.world == 1:
+            return
+        H, hd = k.shape[1], k.shape[2]
+        row = H * hd
+        inter = (k.stride(0) == 2 * row and v.stride(0) == 2 * row and k.stride(1) == hd and
+                 v.data_ptr() == k.data_ptr() + row * k.element_size())
+        if inter:
+            both = torch.as_strided(k, (M, 2 * row), (2 * row, 1), k.storage_offset() + row0 * 2 * row)
+            self.all_gather_rows_(both)
+        else:
+            if k.stride(0) != row or v.stride(0) != row:
+                raise ValueError("gather_kv needs dense or K/V-interleaved cache rows")
+            self.all_gather_rows_(k[row0:row0 + M])
+            self.all_gather_rows_(v[row0:row0 + M])
+
+
+class SimulatedContextParallel:
+    """Runs all `world` token shards inside ONE process in lockstep (test support on a single GPU): every shard's
+    kernels write straight into the shared cache / head buffer, so the collectives are no-ops.  Exercises the
+    sharded launch geometry (row offsets, per-frame lookups, cache row placement) of the phase API."""
+
+    def __init__(self, world):
+        self.world, self.rank = world, 0
+
+    def shard(self, M):
+        return shard_rows(M, self.world, 0)
+
+    def local_ranks(self):
+        return list(range(self.world))
+
+    def all_gather_rows_(self, buf):
+        return buf
+
+    def gather_kv(self, k, v, row0, M):
+        return None

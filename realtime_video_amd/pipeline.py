@@ -54,8 +54,12 @@ class CausalInferencePipeline:
                 c["local_end_index"] = 0
             return
         L = self.num_transformer_blocks
-        self._kv_arena = torch.zeros([L, 2] + shape, dtype=dtype, device=device)
-        self.kv_cache1 = [{"k": self._kv_arena[i, 0], "v": self._kv_arena[i, 1],
+        # K and V rows interleaved per cache row ([L, B, kv, 2, H, hd]): a block of new rows of BOTH K and V is one
+        # contiguous region, i.e. one all-gather message per layer under context parallelism; the dict entries
+        # stay [B, kv, H, hd] views (row stride 2*H*hd), which the attention kernel reads in place.
+        b, kvs, h, hd = shape
+        self._kv_arena = torch.zeros([L, b, kvs, 2, h, hd], dtype=dtype, device=device)
+        self.kv_cache1 = [{"k": self._kv_arena[i, :, :, 0], "v": self._kv_arena[i, :, :, 1],
                            "global_end_index": 0, "local_end_index": 0} for i in range(L)]
         self.k_shape = self.v_shape = shape
 

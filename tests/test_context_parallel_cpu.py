@@ -1,0 +1,140 @@
+"""World-size-2 gloo tests (CPU) of the context-parallel decomposition used on the GPUs
+(realtime_video_amd/parallel.py + the phase API of rtv_dit_*): the token axis is cut into contiguous
+shards, per-token work runs on local rows, ONE in-place all-gather per layer moves the new K/V rows into
+the replicated cache.  The arithmetic here is the CPU oracle; what is under test is the sharding math
+(global frame / position lookup from local rows, cache row placement, collective placement) — the same
+host code drives RCCL on the MI355Xs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import wan_oracle as wo
+from realtime_video_amd.parallel import ContextParallel, shard_rows
+
+GRID = (2, 4, 6)     # F, gh, gw  -> 48 tokens, 24 per frame
+D, H, FFN = 256, 2, 512
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs():
+    cfg = dict(dim=D, ffn_dim=FFN, num_heads=H, num_layers=1)
+    w = wo.make_weights(cfg, seed=4, text_dim=64, dtype=torch.float32)
+    g = torch.Generator().manual_seed(8)
+    M = GRID[0] * GRID[1] * GRID[2]
+    x = torch.randn(1, M, D, generator=g)
+    e = torch.randn(1, GRID[0], 6, D, generator=g) * 0.2
+    ctx = torch.randn(1, 16, D, generator=g)
+    prev_k = torch.randn(1, 20, H, 128, generator=g)   # 20 rows already in the cache (an earlier block)
+    prev_v = torch.randn(1, 20, H, 128, generator=g)
+    return cfg, w, x, e, ctx, prev_k, prev_v
+
+
+def _attn(q, k, v):
+    return wo.attention_sdpa(q, k, v, dtype=None)
+
+
+def _cp_block(w, x_local, e, ctx, k_cache, v_cache, row0, cp, M):
+    """attention_block (causal_model.py:440-492) on the local token shard; mirrors rtv_dit_layer_qkv /
+    gather / rtv_dit_layer_rest."""
+    pre = "blocks.0"
+    r0, rc = cp.shard(M)
+    fs = GRID[1] * GRID[2]
+    frame = (torch.arange(r0, r0 + rc) // fs)
+    em = (w[pre + ".modulation"].unsqueeze(1) + e)[0][frame]            # [rc, 6, D] per-row modulation
+    freqs = wo.rope_table(128)
+
+    def lin(t, name):
+        return torch.nn.functional.linear(t, w[name + ".weight"], w[name + ".bias"])
+
+    def rope_local(t):  # RoPE by global token position: embed the shard in a full-length tensor
+        full = torch.zeros(1, M, H, 128)
+        full[0, r0:r0 + rc] = t
+        return wo.rope_apply(full, GRID, freqs, start_frame=3)[0, r0:r0 + rc]
+
+    h = wo.layer_norm(x_local) * (1 + em[:, 1]) + em[:, 0]
+    sa = pre + ".self_attn"
+    q = wo.rms_norm(lin(h, sa + ".q"), w[sa + ".norm_q.weight"]).view(rc, H, 128)
+    k = wo.rms_norm(lin(h, sa + ".k"), w[sa + ".norm_k.weight"]).view(rc, H, 128)
+    v = lin(h, sa + ".v").view(rc, H, 128)
+    k_cache[0, row0 + r0:row0 + r0 + rc] = rope_local(k)
+    v_cache[0, row0 + r0:row0 + r0 + rc] = v
+    cp.gather_kv(k_cache[0], v_cache[0], row0, M)                       # the one exchange of the layer
+    out = _attn(rope_local(q).unsqueeze(0), k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0]
+    x = x_local + lin(out.flatten(1), sa + ".o") * em[:, 2]
+    ca = pre + ".cross_attn"
+    hq = wo.rms_norm(lin(wo.layer_norm(x, 1e-6, w[pre + ".norm3.weight"], w[pre + ".norm3.bias"]), ca + ".q"),
+                     w[ca + ".norm_q.weight"]).view(1, rc, H, 128)
+    ck = wo.rms_norm(lin(ctx, ca + ".k"), w[ca + ".norm_k.weight"]).view(1, -1, H, 128)
+    cv = lin(ctx, ca + ".v").view(1, -1, H, 128)
+    x = x + lin(_attn(hq, ck, cv)[0].flatten(1), ca + ".o")
+    h = wo.layer_norm(x) * (1 + em[:, 4]) + em[:, 3]
+    y = lin(torch.nn.functional.gelu(lin(h, pre + ".ffn.0"), approximate="tanh"), pre + ".ffn.2")
+    return x + y * em[:, 5]
+
+
+def _worker(rank, world, port, interleaved, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cp = ContextParallel()
+        cfg, w, x, e, ctx, prev_k, prev_v = _inputs()
+        M = x.shape[1]
+        kv_size = 20 + M
+        if interleaved:
+            arena = torch.zeros(1, kv_size, 2, H, 128)
+            kc, vc = arena[:, :, 0], arena[:, :, 1]
+        else:
+            kc, vc = torch.zeros(1, kv_size, H, 128), torch.zeros(1, kv_size, H, 128)
+        kc[:, :20], vc[:, :20] = prev_k, prev_v
+        r0, rc = cp.shard(M)
+        out_local = _cp_block(w, x[0, r0:r0 + rc], e, ctx, kc, vc, 20, cp, M)
+        full = torch.zeros(M, D)
+        full[r0:r0 + rc] = out_local
+        cp.all_gather_rows_(full)                                       # head-output style gather
+        if rank == 0:
+            ret["out"], ret["k"], ret["v"] = full, kc.clone(), vc.clone()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_context_parallel_block_equals_unsharded(interleaved):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), interleaved, ret), nprocs=world, join=True)
+    cfg, w, x, e, ctx, prev_k, prev_v = _inputs()
+    M = x.shape[1]
+    kv = {"k": torch.zeros(1, 20 + M, H, 128), "v": torch.zeros(1, 20 + M, H, 128),
+          "global_end_index": 3 * 24, "local_end_index": 20}
+    kv["k"][:, :20], kv["v"][:, :20] = prev_k, prev_v
+    ca = {"k": None, "v": None, "is_init": False}
+    # unsharded oracle block; FRAME_SEQLEN is hard-coded to 1560 in the reference, so drive start_frame via monkeypatch
+    old = wo.FRAME_SEQLEN
+    wo.FRAME_SEQLEN = 24
+    try:
+        ref = wo.attention_block(w, "blocks.0", x, e, GRID, wo.rope_table(128), ctx, H, kv, ca, 3 * 24, False,
+                                 attn_fn=_attn)
+    finally:
+        wo.FRAME_SEQLEN = old
+    assert torch.allclose(ret["out"], ref[0], atol=2e-5, rtol=1e-5)
+    assert torch.allclose(ret["k"], kv["k"], atol=1e-6) and torch.allclose(ret["v"], kv["v"], atol=1e-6)
+
+
+def test_shard_rows():
+    assert shard_rows(4680, 8, 3) == (1755, 585)
+    assert [shard_rows(4680, 2, r) for r in range(2)] == [(0, 2340), (2340, 2340)]
+    with pytest.raises(ValueError):
+        shard_rows(100, 8, 0)

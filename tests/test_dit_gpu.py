@@ -182,3 +182,30 @@ def test_session_block_loop_matches_oracle():
         assert rel_l2(out.cpu(), ref_blocks[b]) <= 5e-2, b
     assert sess.current_start_frame == 6 and pipe.kv_cache1[0]["local_end_index"] == 9360
     assert pipe.kv_cache1[0]["k"].shape == (1, 9360, cfg["num_heads"], 128)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_context_parallel_phase_api_equals_unsharded(world):
+    """Token-axis sharding (rtv_dit_begin / layer_qkv / layer_rest / head / finish with row ranges): all shards
+    run in lockstep on this one GPU and must reproduce the unsharded forward bit for bit — denoise pass at a
+    non-zero cache offset and the block-causal recompute pass."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.parallel import SimulatedContextParallel
+    cfg, text_dim, tiny_inputs = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    lat, ctx = tiny_inputs()
+    cond = {"prompt_embeds": [ctx.to(DEV)]}
+    outs = []
+    for cp in (None, SimulatedContextParallel(world)):
+        model, wr = _build(cfg, text_dim, w)
+        model.context_parallel = cp
+        kv, ca = _caches(cfg, 9360)
+        t = torch.ones([1, 3], dtype=torch.int64, device=DEV) * 700
+        model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560,
+                                                                     num_frame_per_block=3)
+        f_rc, _ = wr(lat[2].to(DEV), cond, torch.zeros([1, 3], dtype=torch.int64, device=DEV), kv, ca, current_start=4680)
+        model.block_mask = None
+        f_dn, _ = wr(lat[3].to(DEV), cond, t, kv, ca, current_start=4680)
+        outs.append((f_rc.clone(), f_dn.clone(), kv[1]["k"].clone(), kv[1]["v"].clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
