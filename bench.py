@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-tile-cfg", type=int, default=0)
+    ap.add_argument("--parallel", default="cp", choices=["cp", "replicas"],
+                    help="N>1: cp = context-parallel single stream (strong scaling, RCCL all-gather per layer); "
+                         "replicas = one independent stream per GPU (weak scaling, no collective)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,6 +109,10 @@ def main():
     model = CausalWanModel(dim=mc["dim"], ffn_dim=mc["ffn_dim"], num_heads=mc["num_heads"], num_layers=mc["num_layers"],
                            text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)
     model.gemm_tile_cfg = args.gemm_tile_cfg
+    use_cp = world > 1 and args.parallel == "cp"
+    if use_cp:
+        from realtime_video_amd.parallel import ContextParallel
+        model.context_parallel = ContextParallel()
     wr = WanDiffusionWrapper(model, timestep_shift=5.0)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
                                    generator=wr)
@@ -146,7 +153,7 @@ def main():
     prof = {k: ops.prof_read(k) for k in ("gemm", "attn", "layernorm", "rope", "conv", "misc")}
     if rank != 0:
         return
-    total_frames = frames * world  # replicas: every rank generates its own stream
+    total_frames = frames if use_cp or world == 1 else frames * world  # replicas: every rank generates its own stream
     gm = prof["gemm"]
     achieved = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     fwd_per_block = args.denoising_steps + 1
@@ -159,7 +166,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if use_cp else "weak",
         "vs_baseline": (total_frames / elapsed) / 11.0 if args.model == "14b" and world == 1 and not args.no_vae else None,
         "dtype": "bf16",
         "data": "synthetic (random-init weights of the named architecture, N(0,1) latents/noise, N(0,1) prompt embeddings)",
@@ -171,7 +178,9 @@ def main():
             "keep_first_frame": True,
             "note": "first-frame VAE re-encode (release_server.py:572-575, 2.72 of 774.5 TFLOP/block) is not built yet: "
                     "the session runs with keep_first_frame=True",
-            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+            "parallelism": "single GPU" if world == 1 else (
+                f"cp{world}: one stream, token axis sharded {world}-way, K/V all-gather per layer over RCCL, VAE decode "
+                f"replicated on every rank" if use_cp else f"{world} independent replicas"),
             "dit_ms_per_forward": (prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
                                    + prof["misc"]["ms"]) / (args.steps * fwd_per_block),
             "vae_ms_per_block": prof["conv"]["ms"] / args.steps,

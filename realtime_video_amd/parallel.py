@@ -45,7 +45,14 @@ class ContextParallel:
             raise ValueError("all_gather_rows_ needs a contiguous buffer with rows divisible by the world size")
         n = buf.shape[0] // self.world
         mine = buf[self.rank * n:(self.rank + 1) * n]
-        if self._gloo:
+        if self._gloo and buf.is_cuda:
+            # test-only route (several ranks sharing one GPU under gloo): stage through the host
+            host = [torch.empty(mine.shape, dtype=buf.dtype) for _ in range(self.world)]
+            dist.all_gather(host, mine.cpu(), group=self.group)
+            for r in range(self.world):
+                if r != self.rank:
+                    buf[r * n:(r + 1) * n].copy_(host[r])
+        elif self._gloo:
             dist.all_gather([buf[r * n:(r + 1) * n] for r in range(self.world)], mine.clone(), group=self.group)
         else:
             dist.all_gather_into_tensor(buf, mine, group=self.group)
