@@ -341,6 +341,8 @@ class CausalWanModel:
                        start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1])
             return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
 
+        if self.gemm_tile_cfg in (0, 5):
+            ops.ensure_gemm_workspace(u.device)
         if cp is None or cp.world == 1:
             st, wsa = make((0, 0), 0)
             _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)

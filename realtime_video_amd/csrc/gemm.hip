@@ -111,8 +111,15 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
   if (p.gate && p.rows_per_frame <= 0) return set_error(-1, "gemm: gate needs rows_per_frame");
   const bool f16 = dtype == RTV_DTYPE_F16;
   if (dtype != RTV_DTYPE_BF16 && dtype != RTV_DTYPE_F16) return set_error(-1, "gemm: dtype");
+  if (tile_cfg == 0) {
+    // default: the 256x256 ping-pong kernel (+ split-K of the tail round) once there is enough work to fill the
+    // chip with 256x256 tiles, the 128x128 kernel (2 workgroups per CU) otherwise.  Thresholds from
+    // profiles/r01_kbench_*.
+    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    if (!f16 && ((p.K >= 2048 && tiles256 >= 128) || tiles256 >= 640)) return launch_gemm8(p, f16, 1, stream);
+    tile_cfg = 1;
+  }
   switch (tile_cfg) {
-    case 0:
     case 1:
       return f16 ? launch_cfg<true, 128, 128, 64, 2, 2>(p, stream)
                  : launch_cfg<false, 128, 128, 64, 2, 2>(p, stream);
@@ -122,6 +129,14 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     case 3:
       return f16 ? launch_cfg<true, 256, 256, 64, 2, 4>(p, stream)
                  : launch_cfg<false, 256, 256, 64, 2, 4>(p, stream);
+    case 4:
+      return launch_gemm8(p, f16, 4, stream);      // DMA in the LDS segment, no split-K
+    case 5:
+      return launch_gemm8(p, f16, 5, stream);      // + split-K of the tail round
+    case 50:
+      return launch_gemm8(p, f16, 1, stream);      // A/B variants: DMA pieces per LDS segment = 0
+    case 51:
+      return launch_gemm8(p, f16, 3, stream);      //                                            = 1
     default:
       return set_error(-1, "gemm: unknown tile config");
   }

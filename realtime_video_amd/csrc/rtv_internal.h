@@ -21,5 +21,6 @@ struct ProfScope {
 
 struct GemmParams;
 int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream);
+int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream);  // 256x256 ping-pong variant (gemm8.hip)
 
 }  // namespace rtv

@@ -78,6 +78,25 @@ def attn_fwd(q, k, v, out=None, scale=None, causal_block=0, q_offset=0):
 
 
 # --------------------------------------------------------------------------------------- GEMM
+_gemm_ws = {}
+
+
+def ensure_gemm_workspace(device):
+    """Attach the split-K workspace (fp32 partial tiles + arrival counters, 64 MiB) used by tile_cfg 5."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key in _gemm_ws:
+        return
+    lib = _lib.load()
+    lib.rtv_gemm_workspace_bytes.restype = ctypes.c_size_t
+    lib.rtv_gemm_workspace_bytes.argtypes = []
+    n = lib.rtv_gemm_workspace_bytes()
+    ws = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    _lib.call("rtv_gemm_set_workspace", ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(n))
+    _gemm_ws[key] = ws
+
+
 def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame=0, residual=None,
          out=None, tile_cfg=0, row_offset=0):
     """out[M,N] = epi(a[M,K] @ w[N,K]^T) — nn.Linear with fused bias/activation/gate/residual."""
@@ -90,6 +109,8 @@ def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    if tile_cfg in (0, 5):
+        ensure_gemm_workspace(a.device)
     _lib.call("rtv_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K,
               _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame), int(row_offset),
               _ptr(residual), residual.stride(0) if residual is not None else 0,
