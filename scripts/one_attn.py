@@ -1,0 +1,18 @@
+"""Run the attention kernel a few times (for rocprofv3 --pmc passes). usage: one_attn.py [Lq Lkv H] [iters]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from realtime_video_amd import ops  # noqa: E402
+
+lq, lkv, h = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (4680, 9360, 40)
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+q = torch.randn(1, lq, h, 128, device="cuda").to(torch.bfloat16)
+k = torch.randn(1, lkv, h, 128, device="cuda").to(torch.bfloat16)
+v = torch.randn(1, lkv, h, 128, device="cuda").to(torch.bfloat16)
+o = torch.empty_like(q)
+for _ in range(iters):
+    ops.attn_fwd(q, k, v, out=o)
+torch.cuda.synchronize()
