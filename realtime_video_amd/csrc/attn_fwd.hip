@@ -41,6 +41,11 @@ constexpr int ATT_TILE_BYTES = ATT_KT * ATT_D * 2;  // 16 KiB
 constexpr int ATT_THREADS = ATT_WAVES * 64;
 constexpr int ATT_LD_PER_THREAD = ATT_KT * 16 / ATT_THREADS;  // 16-byte chunks per thread per tile (2)
 
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+
 template <bool F16>
 __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
   if constexpr (F16)
@@ -62,7 +67,7 @@ __device__ __forceinline__ u32x2 lds_tr_read(const char* p) {
   return __builtin_bit_cast(u32x2, t);
 }
 
-template <bool F16>
+template <bool F16, bool STAGGER>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // smem: K[2][16 KiB] | V[2][16 KiB]
@@ -121,70 +126,98 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
   }
   const int ntiles = (wg_max_lim + ATT_KT - 1) / ATT_KT;
 
-  // ---- staging geometry: thread moves chunks id = tid + i*512 -> (row = id>>4, chunk = id&15)
+  // ---- staging geometry: thread moves chunks id = tid + i*512 -> (row = id>>4 = tid>>4 + 32 i, chunk = tid&15).
+  //      Full tiles: uniform 64-bit base (SGPR, advanced per tile / per i) + one 32-bit lane offset per operand,
+  //      so the loads cost no per-tile VALU address arithmetic; the ragged last tile clamps rows per lane.
   u32x4 kreg[ATT_LD_PER_THREAD], vreg[ATT_LD_PER_THREAD];
+  const int st_r = tid >> 4, st_c = tid & 15;
+  const uint32_t k_goff = (uint32_t)(st_r * (int)p.k_rs + st_c * 8) * 2u;
+  const uint32_t v_goff = (uint32_t)(st_r * (int)p.v_rs + st_c * 8) * 2u;
   auto load_tile = [&](int j) {
+    const int row0 = j * ATT_KT;
+    if (row0 + ATT_KT <= p.Lkv) {
+      const char* kj = (const char*)(kb + (size_t)row0 * p.k_rs);
+      const char* vj = (const char*)(vb + (size_t)row0 * p.v_rs);
 #pragma unroll
-    for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
-      int id = tid + i * ATT_THREADS;
-      int r = id >> 4, c = id & 15;
-      int kv = min(j * ATT_KT + r, p.Lkv - 1);
-      kreg[i] = *(const u32x4*)(kb + (size_t)kv * p.k_rs + c * 8);
-      vreg[i] = *(const u32x4*)(vb + (size_t)kv * p.v_rs + c * 8);
+      for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
+        kreg[i] = *(const u32x4*)(kj + (size_t)(i * 32) * p.k_rs * 2 + k_goff);
+        vreg[i] = *(const u32x4*)(vj + (size_t)(i * 32) * p.v_rs * 2 + v_goff);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
+        int kv = min(row0 + st_r + i * 32, p.Lkv - 1);
+        kreg[i] = *(const u32x4*)(kb + (size_t)kv * p.k_rs + st_c * 8);
+        vreg[i] = *(const u32x4*)(vb + (size_t)kv * p.v_rs + st_c * 8);
+      }
     }
   };
+  // K: 16-byte chunk index XOR (row & 15)  -> conflict-free ds_read_b128 column reads
+  // V: 64-byte group index XOR (row & 3)   -> conflict-free transpose reads
+  // (row & 15 and row & 3 do not depend on i: rows advance by 32)
+  char* const k_wr = sK + st_r * 256 + ((st_c ^ (st_r & 15)) << 4);
+  char* const v_wr = sV + st_r * 256 + ((st_c << 4) ^ ((st_r & 3) << 6));
   auto write_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
-      int id = tid + i * ATT_THREADS;
-      int r = id >> 4, c = id & 15;
-      // K: 16-byte chunk index XOR (row & 15)  -> conflict-free ds_read_b128 column reads
-      *(u32x4*)(sK + buf * ATT_TILE_BYTES + r * 256 + ((c ^ (r & 15)) << 4)) = kreg[i];
-      // V: 64-byte group index XOR (row & 3)   -> conflict-free transpose reads
-      *(u32x4*)(sV + buf * ATT_TILE_BYTES + r * 256 + ((c << 4) ^ ((r & 3) << 6))) = vreg[i];
+      *(u32x4*)(k_wr + buf * ATT_TILE_BYTES + i * 32 * 256) = kreg[i];
+      *(u32x4*)(v_wr + buf * ATT_TILE_BYTES + i * 32 * 256) = vreg[i];
     }
   };
 
-  // ---- per-lane LDS read offsets
-  // K operand (A): row = kb*32 + l31, chunk = dc*2 + g
-  const int k_row_off = l31 * 256;
-  const int k_swz = l31 & 15;
+  // ---- per-lane LDS read addresses, hoisted out of the tile loop (tile buffer / key block / k-step are
+  //      compile-time offsets that fold into the ds_read immediate)
+  // K operand (A): row = kbk*32 + l31, chunk = (dc*2 + g) ^ (row & 15)
+  const char* k_rd[8];
+#pragma unroll
+  for (int dc = 0; dc < 8; ++dc) k_rd[dc] = sK + l31 * 256 + (((dc * 2 + g) ^ (l31 & 15)) << 4);
   // V^T operand (A) via transpose read: 16-lane group gathers a [4 keys][16 dims] block
   const int i16 = lane & 15, h16 = (lane >> 4) & 1;
-  const int v_lane_off = (4 * g + (i16 >> 2)) * 256 + h16 * 32 + (i16 & 3) * 8;
-  const int v_swz = i16 >> 2;
+  const char* v_rd[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    v_rd[db] = sV + (4 * g + (i16 >> 2)) * 256 + h16 * 32 + (i16 & 3) * 8 + ((db ^ (i16 >> 2)) << 6);
 
   f32x16 oacc[4];
 #pragma unroll
   for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m_run = -1e30f;  // running max of scale*log2e*s
+  float m_run = -1e30f;  // reference point of the exponentials (>= running max - RESCALE_SLACK), log2 domain
   float l_run = 0.f;     // this lane's partial row sum
   const float c = p.scale_log2e;
+  const f32x2 c2 = {c, c};
+  // Lazy rescaling: O and l are only rescaled when some row's maximum has grown by more than 2^8 since the last
+  // rescale (a wave-uniform, rare branch after the first tiles).  The result is the same softmax — any reference
+  // point cancels in O/l — with P <= 256 in the 16-bit MFMA operand and f32 accumulators.
+  constexpr float RESCALE_SLACK = 8.f;
 
-  load_tile(0);
-  write_tile(0);
-  __syncthreads();
+  // STAGGER (kept for A/B, off by default): waves 4-7 run one barrier (= half a tile) behind waves 0-3 so that one
+  // wave's MFMA bursts meet its SIMD partner's softmax.  Measured on MI355X it is 2-3 % SLOWER than the plain
+  // schedule (profiles/r01_attn_variants.txt): the compiler already interleaves the exponentials of tile j with the
+  // O^T += V^T.P^T MFMAs inside each wave, and the extra barrier costs more than the phase shift gains.
+  //     interval 2j  : group 0  A(j)  = load K/V(j+1) -> regs, QK^T(j), softmax     | group 1  B(j-1)
+  //     interval 2j+1: group 0  B(j)  = PV(j), regs -> LDS tile j+1                  | group 1  A(j), regs -> LDS tile j+1
+  const int grp = STAGGER ? (wave >> 2) : 0;
 
-  for (int j = 0; j < ntiles; ++j) {
-    const int buf = j & 1;
+  auto tile = [&](const int j, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
     const bool has_next = (j + 1 < ntiles);
-    if (has_next) load_tile(j + 1);  // in flight during the MFMAs below
+    if (grp == 0 && has_next) load_tile(j + 1);  // in flight during the MFMAs below
 
-    // ---------------- S^T = K . Q^T
-    const char* kt = sK + buf * ATT_TILE_BYTES;
+    // ---------------- S^T = K . Q^T   (two independent accumulator chains, interleaved)
     f32x16 sacc[2];
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk) {
+    for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kbk][r] = 0.f;
 #pragma unroll
-      for (int dc = 0; dc < 8; ++dc) {
-        u32x4 kf = *(const u32x4*)(kt + kbk * 32 * 256 + k_row_off + (((dc * 2 + g) ^ k_swz) << 4));
+    for (int dc = 0; dc < 8; ++dc)
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) {
+        u32x4 kf = *(const u32x4*)(k_rd[dc] + buf * ATT_TILE_BYTES + kbk * 32 * 256);
         sacc[kbk] = mfma32<F16>(kf, qf[dc], sacc[kbk]);
       }
-    }
 
     // ---------------- mask (only on tiles that cross a limit of this wave)
     if ((j + 1) * ATT_KT > wave_min_lim) {
@@ -204,50 +237,68 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * c);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
+    const float m_cand = fmaxf(m_run, mx * c);
+    if (__builtin_amdgcn_ballot_w64(m_cand - m_run > RESCALE_SLACK) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
+      m_run = m_cand;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    }
+    const f32x2 nm2 = {-m_run, -m_run};
+    f32x2 ps2 = {0.f, 0.f};
     u32x4 pf[2][2];  // [kv block][k-step]: 8 x 16-bit = the lane's own 8 keys of that 16-key step
 #pragma unroll
-    for (int kbk = 0; kbk < 2; ++kbk) {
-      float pv[16];
+    for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        pv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[kbk][r], c, -m_new));
-        psum += pv[r];
+      for (int t = 0; t < 8; ++t) {
+        f32x2 x = {sacc[kbk][2 * t], sacc[kbk][2 * t + 1]};
+        x = __builtin_elementwise_fma(x, c2, nm2);  // v_pk_fma_f32
+        f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        ps2 += e;                                   // v_pk_add_f32
+        pf[kbk][t >> 2][t & 3] = pack2<F16>(e[0], e[1]);
       }
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pf[kbk][s][t] = pack2<F16>(pv[s * 8 + 2 * t], pv[s * 8 + 2 * t + 1]);
+    l_run += ps2[0] + ps2[1];
+
+    if (STAGGER) {
+      if (grp == 1 && has_next) write_tile(buf ^ 1);
+      __syncthreads();
+      if (grp == 1 && j + 2 < ntiles) load_tile(j + 2);
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
 
     // ---------------- O^T += V^T . P^T
-    const char* vt = sV + buf * ATT_TILE_BYTES;
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const char* vrow = vt + (kbk * 32 + s * 16) * 256 + v_lane_off;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const int col = ((db ^ v_swz) << 6);
-          u32x2 lo = lds_tr_read(vrow + col);            // keys +0..3  (this lane group's first quad)
-          u32x2 hi = lds_tr_read(vrow + 8 * 256 + col);  // keys +8..11
+          const char* vp = v_rd[db] + buf * ATT_TILE_BYTES + (kbk * 32 + s * 16) * 256;
+          u32x2 lo = lds_tr_read(vp);            // keys +0..3  (this lane group's first quad)
+          u32x2 hi = lds_tr_read(vp + 8 * 256);  // keys +8..11
           u32x4 vf = {lo[0], lo[1], hi[0], hi[1]};
           oacc[db] = mfma32<F16>(vf, pf[kbk][s], oacc[db]);
         }
       }
 
-    if (has_next) write_tile(buf ^ 1);
+    if (grp == 0 && has_next) write_tile(buf ^ 1);
+    __syncthreads();
+  };
+
+  load_tile(0);
+  write_tile(0);
+  __syncthreads();
+  if (STAGGER && grp == 1) {
+    if (ntiles > 1) load_tile(1);
     __syncthreads();
   }
+  for (int j = 0; j < ntiles; j += 2) {
+    tile(j, IntC<0>{});
+    if (j + 1 < ntiles) tile(j + 1, IntC<1>{});
+  }
+  if (STAGGER && grp == 0) __syncthreads();  // group 0 closes the stagger (equal barrier counts)
 
   // ---------------- epilogue: O = O^T / l, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -309,7 +360,7 @@ extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o
   const int lds = 4 * ATT_TILE_BYTES;
   static bool attr_set[2] = {false, false};
   const bool f16 = dtype == RTV_DTYPE_F16;
-  const void* kern = f16 ? (const void*)attn_fwd_kernel<true> : (const void*)attn_fwd_kernel<false>;
+  const void* kern = f16 ? (const void*)attn_fwd_kernel<true, false> : (const void*)attn_fwd_kernel<false, false>;
   if (!attr_set[f16]) {
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(e, "attn_fwd: hipFuncSetAttribute");
@@ -319,8 +370,8 @@ extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o
   double kv_avg = Lkv;  // dense; block-causal work is smaller (reported as dense upper bound / 1)
   ProfScope prof(PROF_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Lq * kv_avg * ATT_D);
   if (f16)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(grid), dim3(ATT_THREADS), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3(grid), dim3(ATT_THREADS), lds, (hipStream_t)stream, p);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(grid), dim3(ATT_THREADS), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3(grid), dim3(ATT_THREADS), lds, (hipStream_t)stream, p);
   return check_launch("attn_fwd");
 }

@@ -1,4 +1,5 @@
-"""Run the attention kernel a few times (for rocprofv3 --pmc passes). usage: one_attn.py [Lq Lkv H] [iters]"""
+"""Run the attention kernel a few times (for rocprofv3 --pmc passes) and print its time.
+usage: one_attn.py [Lq Lkv H] [iters]"""
 import os
 import sys
 
@@ -13,6 +14,14 @@ q = torch.randn(1, lq, h, 128, device="cuda").to(torch.bfloat16)
 k = torch.randn(1, lkv, h, 128, device="cuda").to(torch.bfloat16)
 v = torch.randn(1, lkv, h, 128, device="cuda").to(torch.bfloat16)
 o = torch.empty_like(q)
-for _ in range(iters):
+for _ in range(3):
     ops.attn_fwd(q, k, v, out=o)
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    ops.attn_fwd(q, k, v, out=o)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print(f"attn Lq={lq} Lkv={lkv} H={h}: {ms:.3f} ms  {4.0 * lq * lkv * h * 128 / ms / 1e9:.1f} TF/s  RTV_ABL={os.environ.get('RTV_ABL', '0')}")
