@@ -23,6 +23,28 @@ MODELS = {
     "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, name="Wan2.1-T2V-1.3B arch"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md)
+MFMA_SUSTAINED_TFLOPS = 1770.0  # measured: MFMA-only loop, random operands, clock settles at 1.78 GHz (profiles/r01_mfma_peak.txt)
+
+
+def gemm_algorithmic_bytes(mc, M=4680):
+    """Average algorithmic bytes per DiT-layer projection GEMM launch: operands read once + output written once
+    (A[M,K] + W[N,K] + C[M,N] in bf16, plus the residual read where the epilogue fuses it)."""
+    d, f = mc["dim"], mc["ffn_dim"]
+    shapes = [(3 * d, d, 0), (d, d, 1), (d, d, 0), (d, d, 1), (f, d, 0), (d, f, 1)]  # (N, K, fused residual)
+    tot = sum(2 * (M * K + N * K + M * N + res * M * N) for N, K, res in shapes)
+    return tot / len(shapes)
+
+
+def measured_traffic(model):
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
+    (scripts/profile_bench.sh over this same command; FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_traffic_{model}.json")
+    try:
+        with open(path) as f:
+            g = json.load(f)["classes"]["gemm"]
+        return g["hbm_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline(model_cfg, seconds_budget=30.0):
@@ -157,6 +179,7 @@ def main():
     gm = prof["gemm"]
     achieved = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     fwd_per_block = args.denoising_steps + 1
+    traffic, traffic_src = measured_traffic(args.model) if world == 1 else (None, None)
     result = {
         "metric": "frames/sec at 832x480, 4-step 14B T2V (per-step DiT latency in config)",
         "value": total_frames / elapsed,
@@ -187,13 +210,16 @@ def main():
             "kernel_ms_per_block": {k: v["ms"] / args.steps for k, v in prof.items()},
         },
         "roofline": {
-            "kernel": "gemm_kernel (bf16 MFMA projection GEMM, all DiT linears)",
+            "kernel": "gemm8_kernel / gemm_kernel (bf16 MFMA projection GEMMs with fused epilogues: all DiT linears)",
             "bound": "mfma",
             "achieved": achieved,
             "peak": MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(mc),
+            "frac_of_sustained_mfma": achieved / MFMA_SUSTAINED_TFLOPS,
             "launches": gm["launches"],
             "avg_launch_ms": gm["ms"] / max(gm["launches"], 1),
             "attention_TFLOPs": prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12 if prof["attn"]["ms"] > 0 else None,
