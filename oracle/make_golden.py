@@ -183,11 +183,40 @@ def golden_vae(ref):
     print("vae_decoder.pt", [tuple(p.shape) for p in out["pixels"]])
 
 
+def golden_vae_encoder(ref):
+    """Streaming VAE encoder (VAEEncoderWrapper, demo_utils/vae_block3.py:116-175, over wan/modules/vae.py's
+    WanVAE_ encoder + conv1), fp32 on CPU, 64x96 px frames -> 8x12 latents.  Call 1: fresh cache, non-stream, 5 frames
+    (chunks 1 + 4 -> 2 latent frames; this is also the single-frame first-frame re-encode of release_server.py:574 for
+    its first chunk).  Call 2: stream=True on the returned cache, 8 frames (chunks 4 + 4 -> 2 latent frames)."""
+    import types
+    from oracle import vae_oracle as vo
+    w = vo.make_vae_encoder_weights(seed=1)
+    model = ref.vae.WanVAE_(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                            temperal_downsample=[False, True, True], dropout=0.0).eval()
+    sd = {k: v for k, v in model.state_dict().items() if k.startswith("encoder.") or k.startswith("conv1.")}
+    assert set(sd) == set(w), (sorted(set(sd) ^ set(w))[:8])
+    model.load_state_dict(w, strict=False)
+    enc = ref.vae_block3.VAEEncoderWrapper(types.SimpleNamespace(model=model)).eval()
+    g = torch.Generator().manual_seed(33)
+    frames = [torch.rand(1, 3, 5, 64, 96, generator=g) * 2 - 1, torch.rand(1, 3, 8, 64, 96, generator=g) * 2 - 1]
+    out = {"weights_checksum": float(sum(v.double().abs().sum() for v in w.values())), "mu": [], "cache_shapes": []}
+    with torch.inference_mode():
+        mu, cache = enc(frames[0], [None] * 55, stream=False)
+        out["mu"].append(mu.clone())
+        out["cache_shapes"].append([None if c is None else tuple(c.shape) for c in cache])
+        mu, cache = enc(frames[1], cache, stream=True)
+        out["mu"].append(mu.clone())
+        out["cache_shapes"].append([None if c is None else tuple(c.shape) for c in cache])
+        out["cache_sample"] = [None if c is None else c[0, ::7, :, ::3, ::5].clone() for c in cache]
+    torch.save(out, os.path.join(OUT, "vae_encoder.pt"))
+    print("vae_encoder.pt", [tuple(m.shape) for m in out["mu"]], sum(c is not None for c in cache), "cache slots")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -196,3 +225,5 @@ if __name__ == "__main__":
         golden_rolling(ref)
     if "vae" in which:
         golden_vae(ref)
+    if "vae_enc" in which:
+        golden_vae_encoder(ref)

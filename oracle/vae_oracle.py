@@ -1,5 +1,5 @@
 """CPU ORACLE (test infrastructure only) — restatement of the reference's streaming causal-conv3d VAE
-decoder: `VAEDecoderWrapper` / `VAEDecoder3d` / `Resample` (demo_utils/vae_block3.py:8-114, :177-230,
+(decoder first, the streaming encoder at the end of the file): `VAEDecoderWrapper` / `VAEDecoder3d` / `Resample` (demo_utils/vae_block3.py:8-114, :177-230,
 :334-443) over the building blocks of wan/modules/vae.py (`CausalConv3d` :17-36, `RMS_norm` :39-54,
 `Upsample` :57-63, `ResidualBlock` :175-209, `AttentionBlock` :212-251).
 
@@ -225,4 +225,135 @@ def make_vae_weights(seed=0, dtype=torch.float32):
         if i != 3:
             li += 1
     gamma("decoder.head.0.gamma", 96, 3)
+    return {k: v.to(dtype) for k, v in w.items()}
+
+
+# ======================================================================================= encoder
+# `VAEEncoderWrapper` (demo_utils/vae_block3.py:116-175) over `Encoder3d` (wan/modules/vae.py:254-345) and the
+# 'downsample2d' / 'downsample3d' branches of `Resample` (vae.py:84-96, :104-158); configuration of `_video_vae`
+# (vae.py:591-598): dim=96, z_dim=16 (encoder emits 2*z_dim), dim_mult [1,2,4,4], 2 res blocks per stage,
+# temperal_downsample [False, True, True].  Pinned through oracle/make_golden.py -> tests/golden/vae_encoder.pt.
+ENC_DIMS = [96, 96, 192, 384, 384]
+ENC_TEMPORAL_DOWN = [False, True, True]
+
+
+def resample_down(x, w, pre, mode, feat_cache, feat_idx):
+    """Resample.forward for 'downsample2d' / 'downsample3d', vae.py:132-158: ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2)
+    per frame; downsample3d then runs time_conv (3,1,1)/stride (2,1,1) over [last cached frame | new frames], except on
+    the very first call, which only stores the frame."""
+    b, c, t, h, wd = x.shape
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, wd)
+    x = F.conv2d(F.pad(x, (0, 1, 0, 1)), w[pre + ".resample.1.weight"], w[pre + ".resample.1.bias"], stride=2)
+    x = x.reshape(b, t, c, x.shape[-2], x.shape[-1]).permute(0, 2, 1, 3, 4)
+    if mode == "downsample3d":
+        idx = feat_idx[0]
+        if feat_cache[idx] is None:
+            feat_cache[idx] = x.clone()
+            feat_idx[0] += 1
+        else:
+            cache_x = x[:, :, -1:].clone()
+            x = causal_conv3d(torch.cat([feat_cache[idx][:, :, -1:], x], 2), w[pre + ".time_conv.weight"],
+                              w[pre + ".time_conv.bias"], (0, 0, 0), stride=(2, 1, 1))
+            feat_cache[idx] = cache_x
+            feat_idx[0] += 1
+    return x
+
+
+def encoder3d(x, w, feat_cache, feat_idx):
+    """Encoder3d.forward, vae.py:307-345.  x: [B, 3, T, H, W] -> [B, 32, T', H/8, W/8]."""
+    x = _cached_conv(x, w, "encoder.conv1", feat_cache, feat_idx)
+    li = 0
+    for i in range(4):
+        for _ in range(2):
+            x = residual_block(x, w, f"encoder.downsamples.{li}", feat_cache, feat_idx)
+            li += 1
+        if i != 3:
+            mode = "downsample3d" if ENC_TEMPORAL_DOWN[i] else "downsample2d"
+            x = resample_down(x, w, f"encoder.downsamples.{li}", mode, feat_cache, feat_idx)
+            li += 1
+    x = residual_block(x, w, "encoder.middle.0", feat_cache, feat_idx)
+    x = attention_block(x, w, "encoder.middle.1")
+    x = residual_block(x, w, "encoder.middle.2", feat_cache, feat_idx)
+    x = F.silu(rms_norm(x, w["encoder.head.0.gamma"]))
+    return _cached_conv(x, w, "encoder.head.2", feat_cache, feat_idx)
+
+
+def encoder_wrapper_forward(w, z, feat_cache, stream=False):
+    """VAEEncoderWrapper.forward, vae_block3.py:138-175.  z: [B, 3, T, H, W] pixels in [-1, 1]; feat_cache: list of
+    55 (Tensor | None).  Time is split 1,4,4,... (non-stream, fresh cache) or 4,4,... (stream).  Returns
+    (mu [B, 16, T', H/8, W/8] normalised with the latent mean / std, feat_cache)."""
+    feat_cache = list(feat_cache)
+    t = z.shape[2]
+    iter_ = 1 + (t - 1) // 4
+    offset = 1
+    out = None
+    for i in range(iter_):
+        feat_idx = [0]
+        if i == 0 and feat_cache[0] is None:
+            out = encoder3d(z[:, :, :1], w, feat_cache, feat_idx)
+        else:
+            slice_start = i - 1
+            if stream:
+                offset = 0
+                slice_start = i
+            out_ = encoder3d(z[:, :, offset + 4 * slice_start:offset + 4 * (slice_start + 1)], w, feat_cache, feat_idx)
+            out = out_ if (i == 0 and stream) else torch.cat([out, out_], 2)
+    mu = causal_conv3d(out, w["conv1.weight"], w["conv1.bias"], (0, 0, 0)).chunk(2, dim=1)[0]
+    mean = torch.tensor(MEAN, dtype=z.dtype, device=z.device).view(1, 16, 1, 1, 1)
+    inv_std = 1.0 / torch.tensor(STD, dtype=z.dtype, device=z.device).view(1, 16, 1, 1, 1)
+    return (mu - mean) * inv_std, feat_cache
+
+
+def encoder_conv_specs():
+    """(state_dict prefix, kind, Cin, Cout) for every conv of the encoder in execution order
+    (kinds: c3 3x3x3 causal, c1 1x1x1, d2 Conv2d 3x3 stride 2, t3 time_conv (3,1,1) stride 2)."""
+    specs = [("encoder.conv1", "c3", 3, 96)]
+
+    def res(pre, cin, cout):
+        out = [(pre + ".residual.2", "c3", cin, cout), (pre + ".residual.6", "c3", cout, cout)]
+        if cin != cout:
+            out.append((pre + ".shortcut", "c1", cin, cout))
+        return out
+
+    li = 0
+    for i, (cin, cout) in enumerate(zip(ENC_DIMS[:-1], ENC_DIMS[1:])):
+        for _ in range(2):
+            specs += res(f"encoder.downsamples.{li}", cin, cout)
+            cin = cout
+            li += 1
+        if i != 3:
+            specs.append((f"encoder.downsamples.{li}.resample.1", "d2", cout, cout))
+            if ENC_TEMPORAL_DOWN[i]:
+                specs.append((f"encoder.downsamples.{li}.time_conv", "t3", cout, cout))
+            li += 1
+    specs += res("encoder.middle.0", 384, 384) + res("encoder.middle.2", 384, 384)
+    specs.append(("encoder.head.2", "c3", 384, 32))
+    return specs
+
+
+def make_vae_encoder_weights(seed=1, dtype=torch.float32):
+    """Deterministic synthetic encoder weights (same recipe as make_vae_weights; reference names `encoder.*`,
+    `conv1.*`)."""
+    g = torch.Generator().manual_seed(seed)
+    w = {}
+
+    def conv(name, cout, cin, *k):
+        bound = 1.0 / math.sqrt(cin * math.prod(k))
+        w[name + ".weight"] = (torch.rand(cout, cin, *k, generator=g) * 2 - 1) * bound
+        w[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
+
+    def gamma(name, c, dims):
+        w[name] = 1 + 0.1 * torch.randn(c, *([1] * dims), generator=g)
+
+    kshape = {"c3": (3, 3, 3), "c1": (1, 1, 1), "d2": (3, 3), "t3": (3, 1, 1)}
+    for pre, kind, cin, cout in encoder_conv_specs():
+        conv(pre, cout, cin, *kshape[kind])
+        if pre.endswith(".residual.2"):
+            gamma(pre[:-len(".residual.2")] + ".residual.0.gamma", cin, 3)
+            gamma(pre[:-len(".residual.2")] + ".residual.3.gamma", cout, 3)
+    gamma("encoder.middle.1.norm.gamma", 384, 2)
+    conv("encoder.middle.1.to_qkv", 384 * 3, 384, 1, 1)
+    conv("encoder.middle.1.proj", 384, 384, 1, 1)
+    gamma("encoder.head.0.gamma", 384, 3)
+    conv("conv1", 32, 32, 1, 1, 1)
     return {k: v.to(dtype) for k, v in w.items()}

@@ -30,3 +30,35 @@ def test_vae_decoder_streaming_matches_reference(golden):
 def test_decoder_conv_inventory():
     specs = vo.decoder_conv_specs()
     assert sum(k in ("c3", "t3") for _, k, _, _ in specs) == 32 and sum(k == "c1" for _, k, _, _ in specs) == 1
+
+
+def encoder_inputs():
+    """Same frames as oracle/make_golden.py golden_vae_encoder (seed 33, pixels in [-1, 1])."""
+    g = torch.Generator().manual_seed(33)
+    return [torch.rand(1, 3, 5, 64, 96, generator=g) * 2 - 1, torch.rand(1, 3, 8, 64, 96, generator=g) * 2 - 1]
+
+
+def test_vae_encoder_streaming_matches_reference(golden):
+    """Encoder oracle vs the reference's VAEEncoderWrapper: fresh non-stream call (chunks 1 + 4), then a stream=True
+    call on the returned cache (chunks 4 + 4)."""
+    g = golden("vae_encoder.pt")
+    w = vo.make_vae_encoder_weights(seed=1)
+    cs = float(sum(v.double().abs().sum() for v in w.values()))
+    assert abs(cs - g["weights_checksum"]) <= 1e-6 * g["weights_checksum"]
+    frames = encoder_inputs()
+    cache = [None] * 55
+    for i, (f, stream) in enumerate(zip(frames, (False, True))):
+        mu, cache = vo.encoder_wrapper_forward(w, f, cache, stream=stream)
+        assert mu.shape == g["mu"][i].shape == (1, 16, 2, 8, 12)
+        assert max_abs(mu, g["mu"][i]) <= 1e-4, i
+        assert [None if c is None else tuple(c.shape) for c in cache] == g["cache_shapes"][i]
+    assert sum(c is not None for c in cache) == 24   # 22 cached 3x3x3 convs + 2 downsample3d frame caches
+    for c, gs in zip(cache, g["cache_sample"]):
+        if c is not None:
+            assert max_abs(c[0, ::7, :, ::3, ::5], gs) <= 1e-4
+
+
+def test_encoder_conv_inventory():
+    specs = vo.encoder_conv_specs()
+    kinds = [k for _, k, _, _ in specs]
+    assert kinds.count("c3") == 22 and kinds.count("d2") == 3 and kinds.count("t3") == 2 and kinds.count("c1") == 2
