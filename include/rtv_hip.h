@@ -195,17 +195,24 @@ int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_
                  void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 int rtv_dit_finish(const rtv_dit_config* cfg, const rtv_dit_step* step, const void* head_rows, rtv_stream_t stream);
 
-/* ---- K6/K7: streaming VAE decoder ---------------------------------------------------------------
+/* ---- K6/K7: streaming VAE decoder / encoder -----------------------------------------------------
  * fp16, channels-last activations [T][H][W][C].
- * rtv_conv_cl: implicit-GEMM convolution replacing CausalConv3d / Conv2d / time_conv of the decoder
- *   (wan/modules/vae.py:17-36; demo_utils/vae_block3.py:19-29,:61-72).  `in` is the concat buffer
+ * rtv_conv_cl: implicit-GEMM convolution replacing CausalConv3d / Conv2d / time_conv of the VAE
+ *   (wan/modules/vae.py:17-36,:84-96; demo_utils/vae_block3.py:19-29,:61-72).  `in` is the concat buffer
  *   [cached slices | new slices] for temporal kernels (output frame t reads slices t..t+kt-1); spatial
- *   zero padding kh/2; w is [Cout][kt*kh*kw][Cin]; ups=1 reads the input through a nearest 2x upsampling
- *   (output H,W are the upsampled dims); n_split>0 scatters output channel halves to frames 2t, 2t+1.
+ *   zero padding kh/2; w is [Cout][kt*kh*kw][Cin]; T,H,W are the OUTPUT grid.  `resample`:
+ *     RTV_CONV_NONE         plain conv;
+ *     RTV_CONV_UPSAMPLE2X   input [T][H/2][W/2] read through a nearest 2x upsampling (decoder Resample);
+ *     RTV_CONV_DOWN2X       1x3x3, stride 2, zero pad on the high side only = ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2)
+ *                           of the encoder's Resample (vae.py:84-92), input [T][2H][2W];
+ *     RTV_CONV_TIME_DOWN2X  3x1x1, time stride 2, no padding (encoder time_conv, vae.py:96,:151-156): output frame t
+ *                           reads input slices 2t..2t+2, input [2T+1][H][W].
+ *   n_split>0 scatters output channel halves to frames 2t, 2t+1 (decoder time_conv).
  *   Cin % 32 == 0, Cout % 8 == 0; `zeros` = >=16 zero bytes. */
+enum { RTV_CONV_NONE = 0, RTV_CONV_UPSAMPLE2X = 1, RTV_CONV_DOWN2X = 2, RTV_CONV_TIME_DOWN2X = 3 };
 int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
                 void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
-                int ups, int n_split, const void* zeros, rtv_stream_t stream);
+                int resample, int n_split, const void* zeros, rtv_stream_t stream);
 /* RMS_norm over channels (+SiLU) on channels-last pixels (wan/modules/vae.py:39-54): C in {96,192,384}. */
 int rtv_rmsnorm_silu_cl(const void* x, void* out, const void* gamma, int C, int64_t npix, int apply_silu,
                         rtv_stream_t stream);
@@ -237,6 +244,31 @@ int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, i
 /* z: fp16 [T][16][h][w] latents; pixels: float32 [T'][3][8h][8w] in [-1,1], T' = 4T (4T-3 when first). */
 int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first,
                    void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
+
+/* Streaming VAE encoder: VAEEncoderWrapper.forward (demo_utils/vae_block3.py:116-175) over Encoder3d
+ * (wan/modules/vae.py:254-345; _video_vae config :591-598: dim 96, z_dim 16, temperal_downsample F,T,T).
+ * On the T2V path it re-encodes the first context frame once per block (release_server.py:572-575); in v2v /
+ * webcam mode it encodes every input frame (release_server.py:489-527; v2v.py:138-158). */
+typedef struct rtv_vae_enc_weights {
+  rtv_vae_conv conv1;                 /* encoder.conv1, Cin padded 3 -> 32 */
+  rtv_vae_res down[8];                /* encoder.downsamples.{0,1,3,4,6,7,9,10} (ResidualBlocks) */
+  rtv_vae_conv resample[3];           /* encoder.downsamples.{2,5,8}.resample.1 (Conv2d 3x3 stride 2): [C][9][C] */
+  rtv_vae_conv time_conv[2];          /* encoder.downsamples.{5,8}.time_conv (3,1,1)/stride 2: [C][3][C] */
+  rtv_vae_res mid0, mid2;             /* encoder.middle.{0,2} */
+  rtv_vae_attn attn;                  /* encoder.middle.1 */
+  const void* head_gamma;             /* encoder.head.0 */
+  rtv_vae_conv head;                  /* encoder.head.2: 384 -> 32 */
+  const void *conv1x1_w, *conv1x1_b;  /* float32 [32][32], [32]: the wrapper's conv1 (vae_block3.py:120,:167) */
+  const void *mean, *std;             /* float32 [16] latent statistics (vae_block3.py:121-130) */
+} rtv_vae_enc_weights;
+
+/* Caller-owned arena: 24 feature caches + scratch; zero it before the first chunk of a stream. */
+size_t rtv_vae_enc_arena_bytes(int H, int W);
+int rtv_vae_enc_cache_slot(int H, int W, int slot, size_t* offset, int* C, int* h, int* w, int* nslices);
+/* One time chunk: frames f16 [3][Ttot][H][W] in [-1,1], chunk = frames t0..t0+tn (tn = 1 with first = 1 on fresh caches,
+ * tn = 4 afterwards) -> one latent frame written to mu f16 [16][Tout_tot][H/8][W/8] at index tout. */
+int rtv_vae_encode(const rtv_vae_enc_weights* w, const void* frames, int Ttot, int t0, int tn, int H, int W, int first,
+                   void* arena, size_t arena_bytes, void* mu, int Tout_tot, int tout, rtv_stream_t stream);
 
 /* ---- hardware-layout probes (test support; see csrc/probe.hip) --------------------------------- */
 int rtv_probe_mfma(const void* A /*[32][16] bf16*/, const void* B /*[16][32] bf16*/, void* D /*[32][32] f32*/,

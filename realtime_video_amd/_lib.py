@@ -99,4 +99,8 @@ def check(status, what):
 
 def call(name, *args):
     lib = load()
-    check(getattr(lib, name)(*args), name)
+    fn = getattr(lib, name)
+    if fn.argtypes is None and name in EXTRA_SIGNATURES:   # registered by a module imported after load()
+        fn.argtypes = EXTRA_SIGNATURES[name]
+        fn.restype = c_int
+    check(fn(*args), name)

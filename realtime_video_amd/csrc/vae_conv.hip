@@ -1,4 +1,4 @@
-// Implicit-GEMM causal convolution for the streaming VAE decoder (gfx950, fp16, channels-last).
+// Implicit-GEMM causal convolution for the streaming VAE decoder and encoder (gfx950, fp16, channels-last).
 //
 // Replaces the cuDNN nn.Conv3d / nn.Conv2d calls of the reference decoder: CausalConv3d 3x3x3
 // (wan/modules/vae.py:17-36, used by ResidualBlock :175-209 and VAEDecoder3d vae_block3.py:358,:384),
@@ -12,7 +12,9 @@
 //     spatial zero padding costs no branches in the MMA loop;
 //   * the causal time padding is data, not padding: the conv input is a "concat buffer"
 //     [2 cached slices | T new slices], output frame t reads slices t..t+2 (fused cache-concat);
-//   * nearest-neighbour 2x upsampling is folded into the gather (source = coord >> 1);
+//   * nearest-neighbour 2x upsampling is folded into the gather (source = coord >> 1); the encoder's
+//     ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2) (vae.py:84-92) and its time_conv (3,1,1)/stride (2,1,1)
+//     (vae.py:96, :151-156) are the same gather with a stride on the output grid;
 //   * the time_conv epilogue scatters channel halves to frames 2t / 2t+1 (the reshape/stack of
 //     vae_block3.py:65-67), the ResidualBlock's `x + h` rides in the epilogue as well.
 #include "gemm_core.h"
@@ -33,6 +35,9 @@ struct ConvParams {
   int Cin, Cout;
   int kt, kh, kw;
   int ups;          // 1: input is read through a nearest 2x upsampling
+  int sy, st;       // spatial / temporal stride of the output grid over the input (1 or 2)
+  int pad_h, pad_w; // low-side zero padding (kh/2 for 'same' convs, 0 for the stride-2 downsample: its ZeroPad2d is high-side)
+  int limH, limW;   // taps outside [0,limH) x [0,limW) read zeros (input dims, or output dims when ups)
   int n_split;      // >0: output channel n -> frame 2t + n / n_split, channel n % n_split
   int M;            // T*H*W
   int tiles_m, tiles_n;
@@ -77,7 +82,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   }
   const int cpk = p.Cin / BK;  // K-steps per tap
   const int nk = p.kt * p.kh * p.kw * cpk;
-  const int ph = p.kh >> 1, pw = p.kw >> 1;
 
   auto stage = [&](int ks, int buf) {
     char* sA = smem + buf * Cfg::STAGE_BYTES;
@@ -86,13 +90,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
     const int c0 = (ks - tap * cpk) * BK;
     const int dt = tap / (p.kh * p.kw);
     const int r2 = tap - dt * (p.kh * p.kw);
-    const int dy = r2 / p.kw - ph;
-    const int dx = r2 - (r2 / p.kw) * p.kw - pw;
+    const int dy = r2 / p.kw - p.pad_h;
+    const int dx = r2 - (r2 / p.kw) * p.kw - p.pad_w;
 #pragma unroll
     for (int i = 0; i < Cfg::A_INST; ++i) {
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
-      const int ti = pt[i] + dt;
+      const int yy = py[i] * p.sy + dy, xx = px[i] * p.sy + dx;
+      const bool ok = (yy >= 0) & (yy < p.limH) & (xx >= 0) & (xx < p.limW);
+      const int ti = pt[i] * p.st + dt;
       const size_t off = ((size_t)(ti * p.inH + (yy >> p.ups)) * p.inW + (xx >> p.ups)) * p.Cin + c0 + a_chunk[i];
       const uint16_t* src = ok ? p.in + off : p.zeros;
       dma16(src, sA + (wave * Cfg::A_INST + i) * 1024);
@@ -205,10 +209,15 @@ using namespace rtv;
 /* Standalone C entry (used by the tests): one convolution launch. */
 extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
                            void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
-                           int ups, int n_split, const void* zeros, rtv_stream_t stream) {
+                           int resample, int n_split, const void* zeros, rtv_stream_t stream) {
   if (!in || !w || !out || !zeros) return set_error(-1, "conv: null pointer");
   if ((kt != 1 && kt != 3) || (kh != 1 && kh != 3) || kh != kw) return set_error(-1, "conv: kernel must be 1 or 3 per axis");
+  if (resample < 0 || resample > 3) return set_error(-1, "conv: resample must be 0..3");
+  const int ups = resample == RTV_CONV_UPSAMPLE2X;
   if (ups && ((H | W) & 1)) return set_error(-1, "conv: upsampled output dims must be even");
+  if (resample == RTV_CONV_DOWN2X && (kt != 1 || kh != 3)) return set_error(-1, "conv: the stride-2 downsample is a 1x3x3 conv");
+  if (resample == RTV_CONV_TIME_DOWN2X && (kt != 3 || kh != 1)) return set_error(-1, "conv: the stride-2 time conv is 3x1x1");
+  if (resample != RTV_CONV_NONE && resample != RTV_CONV_UPSAMPLE2X && n_split) return set_error(-1, "conv: n_split with a strided conv");
   ConvParams p;
   p.in = (const uint16_t*)in;
   p.w = (const uint16_t*)w;
@@ -221,8 +230,14 @@ extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, cons
   p.T = T;
   p.H = H;
   p.W = W;
-  p.inH = ups ? H / 2 : H;
-  p.inW = ups ? W / 2 : W;
+  p.inH = ups ? H / 2 : (resample == RTV_CONV_DOWN2X ? 2 * H : H);
+  p.inW = ups ? W / 2 : (resample == RTV_CONV_DOWN2X ? 2 * W : W);
+  p.sy = resample == RTV_CONV_DOWN2X ? 2 : 1;
+  p.st = resample == RTV_CONV_TIME_DOWN2X ? 2 : 1;
+  p.pad_h = resample == RTV_CONV_DOWN2X ? 0 : kh >> 1;
+  p.pad_w = resample == RTV_CONV_DOWN2X ? 0 : kw >> 1;
+  p.limH = ups ? H : p.inH;
+  p.limW = ups ? W : p.inW;
   p.Cin = Cin;
   p.Cout = Cout;
   p.kt = kt;

@@ -198,7 +198,7 @@ using namespace rtv;
 // ConvParams is defined in vae_conv.hip; the orchestrator goes through the C entry rtv_conv_cl.
 extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
                            void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
-                           int ups, int n_split, const void* zeros, rtv_stream_t stream);
+                           int resample, int n_split, const void* zeros, rtv_stream_t stream);
 
 #define RTV_TRY(expr)       \
   do {                      \
@@ -320,7 +320,6 @@ extern "C" int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C
 namespace {
 
 struct Ctx {
-  const rtv_vae_weights* w;
   char* arena;
   const VaeLayout* L;
   int h, wd;
@@ -359,9 +358,13 @@ static int res_block(Ctx& c, int ci, int T, int H, int W, int cin, int cout, con
   RTV_TRY(cached_conv3(c, ci, T, H, W, cin, rw.conv_a, cout, nullptr, tmp, cout));
   RTV_TRY(rtv_rmsnorm_silu_cl(tmp, c.cat(ci + 1) + 2 * sl_out, rw.gamma3, cout, npix, 1, c.stream));
   const uint16_t* hres = x;
-  if (rw.shortcut.w) {  // 1x1x1 conv = plain GEMM over pixels
-    RTV_TRY(rtv_gemm(x, cin, rw.shortcut.w, cin, sc_buf, cout, (int)npix, cout, cin, rw.shortcut.b, 0, nullptr, 0, 0, 0,
-                     nullptr, 0, RTV_DTYPE_F16, 0, c.stream));
+  if (rw.shortcut.w) {  // 1x1x1 conv = plain GEMM over pixels (K = 96 is not a multiple of the GEMM's 64: conv kernel)
+    if (cin % 64 == 0)
+      RTV_TRY(rtv_gemm(x, cin, rw.shortcut.w, cin, sc_buf, cout, (int)npix, cout, cin, rw.shortcut.b, 0, nullptr, 0, 0, 0,
+                       nullptr, 0, RTV_DTYPE_F16, 0, c.stream));
+    else
+      RTV_TRY(rtv_conv_cl(x, rw.shortcut.w, rw.shortcut.b, nullptr, 0, sc_buf, cout, T, H, W, cin, cout, 1, 1, 1, 0, 0,
+                          c.zeros(), c.stream));
     hres = sc_buf;
   }
   RTV_TRY(cached_conv3(c, ci + 1, T, H, W, cout, rw.conv_b, cout, hres, y, cout));
@@ -369,8 +372,7 @@ static int res_block(Ctx& c, int ci, int T, int H, int W, int cin, int cout, con
 }
 
 // AttentionBlock (wan/modules/vae.py:212-251) on one frame: x [P][384] -> y [P][384]
-static int mid_attention(Ctx& c, const uint16_t* x, uint16_t* y) {
-  const rtv_vae_attn& a = c.w->attn;
+static int mid_attention(Ctx& c, const rtv_vae_attn& a, const uint16_t* x, uint16_t* y) {
   const int P = c.h * c.wd, C = 384, ldp = c.L->ldp;
   char* A = c.arena;
   uint16_t *S = (uint16_t*)(A + c.L->s_off), *Pm = (uint16_t*)(A + c.L->p_off), *q = (uint16_t*)(A + c.L->q_off),
@@ -403,7 +405,7 @@ extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, in
   build_layout(h, wd, &L);
   if (arena_bytes < L.total) return set_error(-1, "vae_decode: arena too small (see rtv_vae_arena_bytes)");
   hipStream_t stream = (hipStream_t)stream_;
-  Ctx c{w, (char*)arena, &L, h, wd, stream, 0};
+  Ctx c{(char*)arena, &L, h, wd, stream, 0};
   const int64_t HW8 = (int64_t)(h * 8) * (wd * 8);
   int out_frame = 0;
   // V^T pad columns (K padding of the P.V GEMM) must be zero
@@ -425,7 +427,7 @@ extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, in
     }
     RTV_TRY(cached_conv3(c, 0, 1, H, W, 32, w->conv1, 384, nullptr, a0, 384));
     RTV_TRY(res_block(c, 1, 1, H, W, 384, 384, w->mid0, a0, a1, a2, a3));
-    RTV_TRY(mid_attention(c, a3, a0));
+    RTV_TRY(mid_attention(c, w->attn, a3, a0));
     RTV_TRY(res_block(c, 3, 1, H, W, 384, 384, w->mid2, a0, a1, a2, a3));
     uint16_t* x = a3;  // current activation; the other three buffers are free
     int ci = 5;
@@ -488,6 +490,238 @@ extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, in
       RTV_TRY(check_launch("vae_final"));
       out_frame += Tn;
     }
+  }
+  return 0;
+}
+
+// ====================================================================================== streaming encoder
+// One call = one time chunk of VAEEncoderWrapper.forward (demo_utils/vae_block3.py:138-175): Encoder3d.forward
+// (wan/modules/vae.py:307-345) over 1 frame (first chunk of a stream, fresh caches) or 4 frames, then the wrapper's
+// 1x1x1 conv1, chunk(2) -> mu and the latent normalisation.  24 feature caches: 22 two-slice conv caches and the two
+// single-frame caches of the downsample3d time convs (vae.py:139-158), all kept as the leading slices of the convs'
+// concat buffers in a caller-owned arena.
+namespace rtv {
+
+// frames f16 [3][Ttot][H][W] (frames t0..t0+T) -> channels-last [T][H][W][32] (3 real channels + zero padding)
+__global__ void vae_enc_prep_kernel(const f16_t* __restrict__ frames, int Ttot, int t0, int T, int64_t hw,
+                                    f16_t* __restrict__ out) {
+  const int64_t total = (int64_t)T * hw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / hw, p = i - t * hw;
+    const f16_t r = frames[((int64_t)0 * Ttot + t0 + t) * hw + p];
+    const f16_t g = frames[((int64_t)1 * Ttot + t0 + t) * hw + p];
+    const f16_t b = frames[((int64_t)2 * Ttot + t0 + t) * hw + p];
+    u32x4* dst = (u32x4*)(out + i * 32);
+    dst[0] = u32x4{(uint32_t)r | ((uint32_t)g << 16), (uint32_t)b, 0u, 0u};
+    dst[1] = u32x4{0u, 0u, 0u, 0u};
+    dst[2] = u32x4{0u, 0u, 0u, 0u};
+    dst[3] = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+// head output [T][hw][32] f16 -> conv1 (1x1x1, first 16 of 32 output channels = mu) -> (mu - mean) * (1/std), with the
+// reference's fp16 rounding points (vae_block3.py:168-172) -> mu f16 [16][Tout_tot][hw] at frames tout..tout+T
+__global__ void vae_enc_final_kernel(const f16_t* __restrict__ in, int T, int64_t hw, const float* __restrict__ w1 /*[32][32]*/,
+                                     const float* __restrict__ b1, const float* __restrict__ mean,
+                                     const float* __restrict__ stdv, f16_t* __restrict__ mu, int Tout_tot, int tout) {
+  const int64_t total = (int64_t)T * hw;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t t = i / hw, p = i - t * hw;
+  float x[32];
+  const u32x4* src = (const u32x4*)(in + i * 32);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    u32x4 raw = src[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t u = raw[j];
+      unpack_f16x2(u, x[q * 8 + 2 * j], x[q * 8 + 2 * j + 1]);
+    }
+  }
+#pragma unroll 4
+  for (int co = 0; co < 16; ++co) {
+    float a = b1[co];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) a += w1[co * 32 + c] * x[c];
+    const float inv = round_f16(1.0f / round_f16(stdv[co]));
+    const float v = round_f16(round_f16(round_f16(a) - round_f16(mean[co])) * inv);
+    mu[((int64_t)co * Tout_tot + tout + t) * hw + p] = f32_to_f16(v);
+  }
+}
+
+}  // namespace rtv
+
+namespace {
+
+// concat buffers of the encoder in execution order: (input channels, stage = log2 of the spatial reduction, max new slices)
+static void build_enc_layout(int H, int W, VaeLayout* L) {
+  const int C[24] = {32, 96, 96, 96, 96,        // conv1, downsamples.0 (a,b), .1 (a,b)
+                     96, 192, 192, 192, 192,      // .3 (96->192: a,b), .4 (a,b), .5 time_conv
+                     192, 384, 384, 384, 384,     // .6 (192->384: a,b), .7 (a,b), .8 time_conv
+                     384, 384, 384, 384,          // .9, .10
+                     384, 384, 384, 384, 384};    // middle.0, middle.2, head
+  const int S[24] = {0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3};
+  const int Tm[24] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    return a;
+  };
+  for (int i = 0; i < 32; ++i) {
+    L->cat_off[i] = 0;
+    L->cat_C[i] = L->cat_stage[i] = L->cat_T[i] = 0;
+  }
+  for (int i = 0; i < 24; ++i) {
+    const size_t hw = (size_t)(H >> S[i]) * (W >> S[i]);
+    L->cat_C[i] = C[i];
+    L->cat_stage[i] = S[i];
+    L->cat_T[i] = Tm[i];
+    L->cat_off[i] = take((size_t)(2 + Tm[i]) * hw * C[i] * 2);
+  }
+  // widest activation: 4 x H x W x 96 (stage 0); 4 x H/2 x W/2 x 192 is half of it
+  const size_t amax = (size_t)4 * H * W * 96 * 2;
+  for (int i = 0; i < 4; ++i) L->act_off[i] = take(amax);
+  const size_t P = (size_t)(H >> 3) * (W >> 3);
+  L->ldp = (int)((P + 63) / 64 * 64);
+  L->s_off = take(P * P * 2);
+  L->p_off = take(P * (size_t)L->ldp * 2);
+  L->q_off = take(P * 384 * 2);
+  L->k_off = take(P * 384 * 2);
+  L->vt_off = take((size_t)384 * L->ldp * 2);
+  L->o_off = take(P * 384 * 2);
+  L->xn_off = take(P * 384 * 2);
+  L->head_off = take(P * 32 * 2);
+  L->zeros_off = take(256);
+  L->total = off + 256;
+}
+
+static int enc_dims_ok(int H, int W) {
+  if (H <= 0 || W <= 0 || (H & 7) || (W & 7)) return set_error(-1, "vae_encode: H and W must be positive multiples of 8");
+  if (((H >> 3) * (W >> 3)) % 8) return set_error(-1, "vae_encode: (H/8)*(W/8) must be a multiple of 8");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t rtv_vae_enc_arena_bytes(int H, int W) {
+  if (enc_dims_ok(H, W)) return 0;
+  VaeLayout L;
+  build_enc_layout(H, W, &L);
+  return L.total;
+}
+
+/* byte offset + geometry of encoder feature-cache slot i (0..23): the cached slices are the `nslices` slices that end
+ * at slice 2 of the conv's concat buffer (2 for the 3x3x3 convs, 1 for the downsample3d frame caches, slots 9 and 14:
+ * `offset` already points at that slice). */
+extern "C" int rtv_vae_enc_cache_slot(int H, int W, int slot, size_t* offset, int* C, int* h, int* w, int* nslices) {
+  if (slot < 0 || slot >= 24) return set_error(-1, "vae_enc_cache_slot: slot out of range");
+  RTV_TRY(enc_dims_ok(H, W));
+  VaeLayout L;
+  build_enc_layout(H, W, &L);
+  const int s = L.cat_stage[slot];
+  const bool frame_cache = slot == 9 || slot == 14;
+  *C = L.cat_C[slot];
+  *h = H >> s;
+  *w = W >> s;
+  *nslices = frame_cache ? 1 : 2;
+  *offset = L.cat_off[slot] + (frame_cache ? (size_t)(H >> s) * (W >> s) * L.cat_C[slot] * 2 : 0);
+  return 0;
+}
+
+extern "C" int rtv_vae_encode(const rtv_vae_enc_weights* w, const void* frames, int Ttot, int t0, int tn, int H, int W,
+                              int first, void* arena, size_t arena_bytes, void* mu, int Tout_tot, int tout,
+                              rtv_stream_t stream_) {
+  if (!w || !frames || !arena || !mu) return set_error(-1, "vae_encode: null argument");
+  RTV_TRY(enc_dims_ok(H, W));
+  if (first ? tn != 1 : tn != 4)
+    return set_error(-1, "vae_encode: a chunk is 1 frame on fresh caches (first=1) or 4 frames (vae_block3.py:146-166)");
+  if (t0 < 0 || t0 + tn > Ttot) return set_error(-1, "vae_encode: frame range outside the clip");
+  if (tout < 0 || tout + 1 > Tout_tot) return set_error(-1, "vae_encode: latent frame index outside the output");
+  if (((uintptr_t)arena) & 255) return set_error(-1, "vae_encode: arena must be 256-byte aligned");
+  VaeLayout L;
+  build_enc_layout(H, W, &L);
+  if (arena_bytes < L.total) return set_error(-1, "vae_encode: arena too small (see rtv_vae_enc_arena_bytes)");
+  hipStream_t stream = (hipStream_t)stream_;
+  const int h = H >> 3, wd = W >> 3;
+  Ctx c{(char*)arena, &L, h, wd, stream, 0};
+  if (L.ldp != h * wd)
+    if (hipMemsetAsync((char*)arena + L.vt_off, 0, (size_t)384 * L.ldp * 2, stream) != hipSuccess)
+      return set_error(-1, "vae_encode: memset failed");
+
+  int T = tn, Hs = H, Ws = W;
+  // pixels -> conv1's concat buffer (channels-last, 32-channel padded)
+  hipLaunchKernelGGL(vae_enc_prep_kernel, dim3(2048), dim3(256), 0, stream, (const f16_t*)frames, Ttot, t0, T,
+                     (int64_t)H * W, (f16_t*)(c.cat(0) + 2 * (size_t)H * W * 32));
+  RTV_TRY(check_launch("vae_enc_prep"));
+  uint16_t* x = c.act(0);
+  RTV_TRY(cached_conv3(c, 0, T, Hs, Ws, 32, w->conv1, 96, nullptr, x, 96));
+  auto others = [&](uint16_t** out3) {  // the three activation buffers that do not hold x
+    int nb = 0;
+    for (int i = 0; i < 4 && nb < 3; ++i)
+      if (c.act(i) != x) out3[nb++] = c.act(i);
+  };
+  const int dims[5] = {96, 96, 192, 384, 384};
+  int ci = 1;
+  for (int s = 0; s < 4; ++s) {
+    int cin = dims[s];
+    const int cout = dims[s + 1];
+    for (int r = 0; r < 2; ++r) {
+      uint16_t* b[3];
+      others(b);
+      RTV_TRY(res_block(c, ci, T, Hs, Ws, cin, cout, w->down[s * 2 + r], x, b[0], b[1], b[2]));
+      x = b[2];
+      ci += 2;
+      cin = cout;
+    }
+    if (s == 3) break;
+    uint16_t* b[3];
+    others(b);
+    if (s == 0) {  // downsample2d: ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2), per frame
+      RTV_TRY(rtv_conv_cl(x, w->resample[s].w, w->resample[s].b, nullptr, 0, b[0], cout, T, Hs / 2, Ws / 2, cout, cout, 1,
+                          3, 3, RTV_CONV_DOWN2X, 0, c.zeros(), stream));
+      x = b[0];
+    } else {       // downsample3d: the spatial conv writes the new slices of the time_conv's concat buffer
+      const size_t sl = (size_t)(Hs / 2) * (Ws / 2) * cout;  // elements per slice at the reduced resolution
+      uint16_t* buf = c.cat(ci);
+      RTV_TRY(rtv_conv_cl(x, w->resample[s].w, w->resample[s].b, nullptr, 0, buf + 2 * sl, cout, T, Hs / 2, Ws / 2, cout,
+                          cout, 1, 3, 3, RTV_CONV_DOWN2X, 0, c.zeros(), stream));
+      if (first) {  // vae.py:142-144: the first frame is only stored
+        if (hipMemcpyAsync(b[0], buf + 2 * sl, sl * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+          return set_error(-1, "vae_encode: memcpy failed");
+      } else {      // time_conv (3,1,1) / stride (2,1,1) over [last cached frame | T new frames]
+        RTV_TRY(rtv_conv_cl(buf + sl, w->time_conv[s - 1].w, w->time_conv[s - 1].b, nullptr, 0, b[0], cout, T / 2, Hs / 2,
+                            Ws / 2, cout, cout, 3, 1, 1, RTV_CONV_TIME_DOWN2X, 0, c.zeros(), stream));
+      }
+      // cache <- last new frame
+      if (hipMemcpyAsync(buf + sl, buf + (size_t)(1 + T) * sl, sl * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+        return set_error(-1, "vae_encode: memcpy failed");
+      x = b[0];
+      if (!first) T /= 2;
+      ci += 1;
+    }
+    Hs /= 2;
+    Ws /= 2;
+  }
+  {
+    uint16_t* b[3];
+    others(b);
+    RTV_TRY(res_block(c, ci, T, Hs, Ws, 384, 384, w->mid0, x, b[0], b[1], b[2]));
+    RTV_TRY(mid_attention(c, w->attn, b[2], b[0]));
+    RTV_TRY(res_block(c, ci + 2, T, Hs, Ws, 384, 384, w->mid2, b[0], b[1], b[2], x));
+    ci += 4;
+  }
+  {
+    const size_t sl = (size_t)Hs * Ws * 384;
+    RTV_TRY(rtv_rmsnorm_silu_cl(x, c.cat(ci) + 2 * sl, w->head_gamma, 384, (int64_t)T * Hs * Ws, 1, stream));
+    uint16_t* ho = (uint16_t*)((char*)arena + L.head_off);
+    RTV_TRY(cached_conv3(c, ci, T, Hs, Ws, 384, w->head, 32, nullptr, ho, 32));
+    const int64_t hw = (int64_t)Hs * Ws;
+    hipLaunchKernelGGL(vae_enc_final_kernel, dim3((unsigned)((T * hw + 127) / 128)), dim3(128), 0, stream, (const f16_t*)ho,
+                       T, hw, (const float*)w->conv1x1_w, (const float*)w->conv1x1_b, (const float*)w->mean,
+                       (const float*)w->std, (f16_t*)mu, Tout_tot, tout);
+    RTV_TRY(check_launch("vae_enc_final"));
   }
   return 0;
 }

@@ -2,6 +2,7 @@
 and the host-side mirrors (scheduler, cache bookkeeping, weight packing, plugin argument checks) behave like
 the reference."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -20,6 +21,10 @@ def test_library_exports_every_declared_symbol():
     lib.rtv_vae_arena_bytes.restype = ctypes.c_size_t
     lib.rtv_vae_arena_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
     assert 5e9 < lib.rtv_vae_arena_bytes(60, 104) < 12e9   # sized for 288 GB HBM: ~7 GB per decode stream
+    assert "rtv_vae_encode" in syms and "rtv_vae_enc_cache_slot" in syms
+    lib.rtv_vae_enc_arena_bytes.restype = ctypes.c_size_t
+    lib.rtv_vae_enc_arena_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+    assert 3e9 < lib.rtv_vae_enc_arena_bytes(480, 832) < 8e9 and lib.rtv_vae_enc_arena_bytes(481, 832) == 0
 
 
 def test_product_path_refuses_cpu_tensors():
@@ -112,6 +117,29 @@ def test_vae_state_dict_spec_matches_oracle_weights():
     spec = dict(VAEDecoderWrapper.state_dict_spec())
     w = vo.make_vae_weights(0)
     assert set(spec) == set(w) and all(tuple(w[k].shape) == tuple(v) for k, v in spec.items())
+
+
+def test_vae_encoder_state_dict_spec_and_cache_slots():
+    from oracle import vae_oracle as vo
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    import realtime_video_amd.vae_encoder  # noqa: F401  (registers signatures)
+    spec = dict(VAEEncoderWrapper.state_dict_spec())
+    w = vo.make_vae_encoder_weights(1)
+    assert set(spec) == set(w) and all(tuple(w[k].shape) == tuple(v) for k, v in spec.items())
+    # cache-slot geometry = the shapes the reference leaves in feat_cache (golden cache_shapes), channels 3 -> 32 padded
+    off, C, h, wd, ns = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    shapes = []
+    for i in range(24):
+        _lib.call("rtv_vae_enc_cache_slot", 64, 96, i, ctypes.byref(off), ctypes.byref(C), ctypes.byref(h), ctypes.byref(wd),
+                  ctypes.byref(ns))
+        shapes.append((C.value, ns.value, h.value, wd.value))
+        assert off.value % 2 == 0
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "vae_encoder.pt"))
+    want = [(32 if s[1] == 3 else s[1], s[2], s[3], s[4]) for s in g["cache_shapes"][-1] if s is not None]
+    assert shapes == want
+    with pytest.raises(RuntimeError):
+        _lib.call("rtv_vae_enc_cache_slot", 64, 96, 24, ctypes.byref(off), ctypes.byref(C), ctypes.byref(h),
+                  ctypes.byref(wd), ctypes.byref(ns))
 
 
 def test_rope_table_matches_reference_freqs(golden):

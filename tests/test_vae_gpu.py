@@ -139,3 +139,83 @@ def test_streaming_decoder_matches_reference_golden(golden):
     # a fresh stream restarts from the 9-frame first block
     px, _ = dec(vae_inputs()[0].half().to(DEV), *([None] * 55))
     assert px.shape[1] == 9 and max_abs(px.cpu(), g["pixels"][0]) <= 3e-2
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("C,T,H,W", [(96, 4, 16, 24), (192, 1, 8, 12), (384, 2, 8, 12)])
+def test_downsample_conv2d_stride2(C, T, H, W):
+    """ZeroPad2d((0,1,0,1)) + Conv2d(3, stride 2) of the encoder's Resample (wan/modules/vae.py:84-92)."""
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(T, 2 * H, 2 * W, C, generator=g).half().to(DEV)
+    w = (torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5).half().to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).half().to(DEV)
+    out = _conv_cl(x, w, b, T, H, W, 1, 3, 3, ups=2)
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2).float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2)
+    assert out.shape == (T, H, W, C) and max_abs(out, ref.permute(0, 2, 3, 1)) <= 1e-2
+
+
+@pytest.mark.parametrize("C,T", [(192, 2), (384, 1)])
+def test_time_conv_stride2(C, T):
+    """Encoder time_conv (3,1,1) / stride (2,1,1) over [cached frame | 2T new frames] (vae.py:96, :151-156)."""
+    g = torch.Generator().manual_seed(C)
+    H, W = 6, 8
+    x = torch.randn(2 * T + 1, H, W, C, generator=g).half().to(DEV)
+    w = (torch.randn(C, C, 3, 1, 1, generator=g) * (3 * C) ** -0.5).half().to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).half().to(DEV)
+    out = _conv_cl(x, w, b, T, H, W, 3, 1, 1, ups=3)
+    ref = F.conv3d(x.permute(3, 0, 1, 2).unsqueeze(0).float(), w.float(), b.float(), stride=(2, 1, 1))[0]
+    assert out.shape == (T, H, W, C) and max_abs(out, ref.permute(1, 2, 3, 0)) <= 1e-2
+
+
+def test_conv1x1_k96_shortcut():
+    """1x1x1 shortcut with Cin = 96 (encoder ResidualBlock 96 -> 192) runs through the conv kernel."""
+    g = torch.Generator().manual_seed(5)
+    T, H, W = 2, 8, 12
+    x = torch.randn(T, H, W, 96, generator=g).half().to(DEV)
+    w = (torch.randn(192, 96, 1, 1, 1, generator=g) * 96 ** -0.5).half().to(DEV)
+    b = (torch.randn(192, generator=g) * 0.1).half().to(DEV)
+    out = _conv_cl(x, w, b, T, H, W, 1, 1, 1)
+    ref = x.float() @ w.float().reshape(192, 96).t() + b.float()
+    assert max_abs(out, ref) <= 1e-2
+
+
+def test_streaming_encoder_matches_reference_golden(golden):
+    """VAEEncoderWrapper (native) vs the golden minted from the reference's VAEEncoderWrapper (fp32 CPU): fresh
+    non-stream call (chunks 1 + 4), then stream=True on the returned cache (chunks 4 + 4).  Stated tolerance: fp16
+    pipeline vs fp32 reference on normalised latents (|mu| ~ 0.2-1): max-abs <= max(2 x eager-fp16 error, 2e-2), cap
+    5e-2; cache contents rel-L2 <= 2e-2."""
+    from oracle import vae_oracle as vo
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    from test_vae_oracle_vs_golden import encoder_inputs
+    g = golden("vae_encoder.pt")
+    enc = VAEEncoderWrapper(device=DEV)
+    enc.load_state_dict(vo.make_vae_encoder_weights(seed=1))
+    w16 = {k: v.half().to(DEV) for k, v in vo.make_vae_encoder_weights(seed=1).items()}
+    cache, cache16 = [None] * 55, [None] * 55
+    for i, (f, stream) in enumerate(zip(encoder_inputs(), (False, True))):
+        f16 = f.half().to(DEV)
+        mu, cache = enc(f16, cache, stream=stream)
+        mu16, cache16 = vo.encoder_wrapper_forward(w16, f16, cache16, stream=stream)
+        ref = g["mu"][i]
+        assert mu.shape == ref.shape and mu.dtype == torch.float16
+        err, err16 = max_abs(mu.float().cpu(), ref), max_abs(mu16.float().cpu(), ref)
+        assert err <= max(2 * err16, 2e-2) and err <= 5e-2, (i, err, err16)
+        assert rel_l2(mu.float().cpu(), ref) <= 2e-2
+        assert [None if c is None else tuple(c.shape) for c in cache] == g["cache_shapes"][i]
+    assert sum(c is not None for c in cache) == 24
+    for c, gs in zip(cache, g["cache_sample"]):
+        if c is not None:
+            assert rel_l2(c[0, ::7, :, ::3, ::5].float().cpu(), gs) <= 2e-2
+    # single-frame encode on a fresh cache = the first-frame re-encode of release_server.py:572-575
+    mu1, _ = enc(encoder_inputs()[0][:, :, :1].half().to(DEV), [None] * 55, stream=False)
+    assert mu1.shape == (1, 16, 1, 8, 12) and max_abs(mu1.float().cpu(), g["mu"][0][:, :, :1]) <= 3e-2
+
+
+def test_encoder_rejects_cpu_and_bad_chunks():
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    enc = VAEEncoderWrapper(device=DEV).init_random_weights()
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, 3, 1, 64, 96, dtype=torch.float16), [None] * 55)
+    mu, cache = enc(torch.zeros(1, 3, 1, 64, 96, dtype=torch.float16, device=DEV), [None] * 55)
+    with pytest.raises(ValueError):   # non-stream continuation: the reference slices z[:, :, -3:1] here
+        enc(torch.zeros(1, 3, 4, 64, 96, dtype=torch.float16, device=DEV), cache, stream=False)
