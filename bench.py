@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--denoising-steps", type=int, default=4)
     ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep-first-frame", action="store_true",
+                    help="GenerateParams.keep_first_frame=True: skip the per-block first-frame VAE re-encode (A/B runs)")
     ap.add_argument("--gemm-tile-cfg", type=int, default=0)
     ap.add_argument("--parallel", default="cp", choices=["cp", "replicas"],
                     help="N>1: cp = context-parallel single stream (strong scaling, RCCL all-gather per layer); "
@@ -125,6 +127,7 @@ def main():
     from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
     from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
     from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
     from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
 
     mc = MODELS[args.model]
@@ -139,13 +142,16 @@ def main():
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
                                    generator=wr)
     vae = None if args.no_vae else VAEDecoderWrapper(dev).init_random_weights(seed=1)
+    vae_enc = None if args.no_vae else VAEEncoderWrapper(device=dev).init_random_weights(seed=2)
+    keep_first = bool(args.no_vae or args.keep_first_frame)   # reference default: False = re-encode the first context frame every block
     g = torch.Generator(device=dev).manual_seed(42)
     prompt = torch.zeros(1, 512, 4096, dtype=torch.bfloat16, device=dev)
     prompt[:, :64] = torch.randn(1, 64, 4096, generator=g, device=dev).to(torch.bfloat16)
-    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(prompt), vae_decoder=vae)
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(prompt), vae_decoder=vae,
+                    vae_encoder=vae_enc)
     n_blocks = args.warmup + args.steps
     params = GenerateParams(prompt="synthetic", seed=42, kv_cache_num_frames=args.kv_cache_num_frames,
-                            num_blocks=n_blocks, num_denoising_steps=args.denoising_steps, keep_first_frame=True)
+                            num_blocks=n_blocks, num_denoising_steps=args.denoising_steps, keep_first_frame=keep_first)
     sess = GenerationSession(params, models, device=dev)
 
     def barrier():
@@ -196,11 +202,12 @@ def main():
         "config": {
             "workload": f"{mc['name']}, 832x480 (latent 60x104, 1560 tokens/frame), {args.denoising_steps} denoising steps, "
                         f"kv_cache_num_frames={args.kv_cache_num_frames}, 3 latent frames (12 pixel frames) per block, "
-                        f"KV-recompute forward every block, streaming VAE decode {'OFF (INVALID: diagnostic run)' if args.no_vae else 'on (fp16)'}",
+                        f"KV-recompute forward every block, first-frame VAE re-encode every block, streaming VAE decode {'OFF (INVALID: diagnostic run)' if args.no_vae else 'on (fp16)'}",
             "model": args.model,
-            "keep_first_frame": True,
-            "note": "first-frame VAE re-encode (release_server.py:572-575, 2.72 of 774.5 TFLOP/block) is not built yet: "
-                    "the session runs with keep_first_frame=True",
+            "keep_first_frame": keep_first,
+            "note": "reference default keep_first_frame=False: from block 2 on every block re-encodes the first context "
+                    "frame through the streaming VAE encoder (release_server.py:572-575); warm-up >= 2 blocks puts the timed "
+                    "blocks in that steady state",
             "parallelism": "single GPU" if world == 1 else (
                 f"cp{world}: one stream, token axis sharded {world}-way, K/V all-gather per layer over RCCL, VAE decode "
                 f"replicated on every rank" if use_cp else f"{world} independent replicas"),

@@ -13,6 +13,7 @@ from typing import Callable, Optional
 import torch
 
 from .scheduler import FlowMatchScheduler, get_denoising_schedule
+from .vae_encoder import encode_video_latent
 
 
 @dataclass
@@ -106,8 +107,11 @@ class GenerationSession:
         if models.vae_encoder is None:
             raise RuntimeError("first-frame re-encode needs a VAE encoder (release_server.py:572-575); "
                                "set keep_first_frame=True to run without one")
-        first = models.vae_encoder(self.frame_context_cache[0][0].half())  # -> [1, 1, 16, h, w]
-        return torch.cat((first.to(tail), tail), dim=1)
+        # re-encode the oldest pixel frame of the context window as a fresh first frame (release_server.py:574)
+        first = encode_video_latent(models.vae_encoder, [None] * 55, resample_to=16, max_frames=81, video_path_or_url=None,
+                                    frames=self.frame_context_cache[0][0].half(), height=self.height, width=self.width,
+                                    stream=False)[0].transpose(0, 1)[None]          # [1, 1, 16, h, w]
+        return torch.cat((first, tail), dim=1).to(self.all_latents)
 
     # release_server.py:588-633
     def recompute_kv_cache(self, models):

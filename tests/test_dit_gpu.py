@@ -209,3 +209,63 @@ def test_context_parallel_phase_api_equals_unsharded(world):
         outs.append((f_rc.clone(), f_dn.clone(), kv[1]["k"].clone(), kv[1]["v"].clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_session_first_frame_reencode_path():
+    """keep_first_frame=False (the reference default): from block 2 on, get_clean_context_frames re-encodes the oldest
+    pixel frame of the context window through the VAE encoder (release_server.py:572-575).  The re-encoded latent is
+    checked against the encoder oracle (eager fp16 on this GPU) on the same pixel frame; the DiT blocks are checked
+    against the CPU session oracle fed with that latent."""
+    from oracle import vae_oracle as vo
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    g = torch.Generator().manual_seed(5)
+    ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
+    noise = torch.randn(1, 9, 16, 60, 104, generator=g).to(torch.bfloat16)
+
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
+                                   DEV, generator=wr, text_encoder=None, vae=None)
+    padded = torch.zeros(1, 512, text_dim, dtype=torch.bfloat16)
+    padded[0, :64] = ctx
+    enc_w = vo.make_vae_encoder_weights(seed=1)
+    enc = VAEEncoderWrapper(device=DEV)
+    enc.load_state_dict(enc_w)
+    calls = []
+
+    def recording_encoder(frames, cache, stream=False):
+        mu, c = enc(frames, cache, stream=stream)
+        calls.append((frames.clone(), mu.clone()))
+        return mu, c
+
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(padded.to(DEV)),
+                    vae_decoder=VAEDecoderWrapper(DEV).init_random_weights(), vae_encoder=recording_encoder)
+    sess = GenerationSession(GenerateParams(seed=9, num_blocks=3, num_denoising_steps=4, keep_first_frame=False),
+                             models, device=DEV)
+    sess.noise = noise.to(DEV)
+    cpu_rnd = torch.Generator().manual_seed(9)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    outs, oldest = [], None
+    for b in range(3):
+        if b == 2:
+            oldest = sess.frame_context_cache[0].clone()       # [1, 1, 3, 480, 832]: what block 2 must re-encode
+        outs.append(sess.generate_block())
+    assert [o.shape[1] for o in outs] == [6, 12, 12]            # 9 - 3 dropped, then 12 per block
+    assert len(calls) == 1                                       # blocks 0, 1 keep the first latent; block 2 re-encodes
+    frames, mu = calls[0]
+    assert frames.shape == (1, 3, 1, 480, 832) and mu.shape == (1, 16, 1, 60, 104)
+    assert torch.equal(frames[0, :, 0], oldest[0, 0].half())
+    w16 = {k: v.half().to(DEV) for k, v in enc_w.items()}
+    mu_ref, _ = vo.encoder_wrapper_forward(w16, frames, [None] * 55, stream=False)
+    assert rel_l2(mu.float(), mu_ref.float()) <= 2e-2
+
+    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9,
+                           first_frame_fn=lambda idx: mu.permute(0, 2, 1, 3, 4).cpu().to(torch.bfloat16))
+    for b in range(3):
+        ref = ora.generate_block()
+        assert rel_l2(sess.all_latents[:, 3 * b:3 * b + 3].cpu(), ref) <= 5e-2, b
