@@ -70,9 +70,10 @@ int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
              const void* residual, int ldr,
              int dtype, int tile_cfg, rtv_stream_t stream);
 
-/* tile_cfg: 0/1 = 128x128 tiles (2 workgroups per CU); 2/3 = 256x128 / 256x256 simple double buffer;
+/* tile_cfg: 0 = default (gemm8 + split-K when the problem fills the chip with 256x256 tiles, else 128x128);
+ * 1 = 128x128 tiles (2 workgroups per CU); 2/3 = 256x128 / 256x256 simple double buffer;
  * 4 = 256x256 ping-pong pipeline (gemm8.hip); 5 = 4 + split-K of the last partial round of tiles (needs the
- * workspace below).  The split-K partial sums live in a caller-owned fp32 workspace: */
+ * workspace below); 6 / 7 = 256x256 software-pipelined variant (gemm9.hip) without / with that split-K.  The split-K partial sums live in a caller-owned fp32 workspace: */
 size_t rtv_gemm_workspace_bytes(void);
 int rtv_gemm_set_workspace(void* ptr, size_t bytes);   /* ptr == NULL detaches it */
 

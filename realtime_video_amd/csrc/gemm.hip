@@ -133,6 +133,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
       return launch_gemm8(p, f16, 4, stream);      // DMA in the LDS segment, no split-K
     case 5:
       return launch_gemm8(p, f16, 5, stream);      // + split-K of the tail round
+    case 6:
+      return launch_gemm9(p, f16, false, stream);  // 256x256, k32-slab ring of 5, register-prefetched fragments
+    case 7:
+      return launch_gemm9(p, f16, true, stream);   // + split-K of the tail round
     case 50:
       return launch_gemm8(p, f16, 1, stream);      // A/B variants: DMA pieces per LDS segment = 0
     case 51:

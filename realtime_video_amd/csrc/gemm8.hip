@@ -24,6 +24,7 @@
 // in a caller-provided workspace and the last arriver (agent-scope release / acquire + arrival counter)
 // sums them and runs the epilogue.
 #include "gemm_core.h"
+#include "gemm_split.h"
 #include "rtv_internal.h"
 
 namespace rtv {
@@ -34,23 +35,15 @@ constexpr int HALF_ROWS = 128;
 constexpr int HALF_BYTES = HALF_ROWS * BK * 2;  // 16 KiB
 constexpr int LDS_BYTES = 8 * HALF_BYTES;       // 128 KiB
 constexpr int THREADS = 512;
-constexpr int SLAB_FLOATS = BM * BN;            // fp32 partial tile (256 KiB)
-constexpr int MAX_SPLIT_UNITS = 256;
 
 __device__ __forceinline__ int slot_off(int buf, int h) { return (buf * 4 + h) * HALF_BYTES; }
 // swizzled 16-byte chunk position inside a 128-byte row (involution; conflict-free ds_read_b128)
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
-struct SplitArgs {
-  int first_unit;   // block ids >= first_unit are split units; full tiles before
-  int S;            // K segments per split tile (1 = no splitting)
-  float* slabs;     // [units][SLAB_FLOATS]
-  int* counters;    // [split tiles], zeroed by a memset node before the launch
-};
 }  // namespace g8
 
 template <bool F16, int NL>
-__global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, g8::SplitArgs sp) {
+__global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
   typedef TileCfg<256, 256, 64, 2, 4> Cfg;  // epilogue geometry: 4 x 2 blocks of 32x32 per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -64,17 +57,8 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, g8:
   // ---- workgroup -> (tile, K segment)
   const int ntiles = p.tiles_m * p.tiles_n;
   const int nk_total = p.K / BK;
-  int tile_id, seg = 0, unit = -1;
-  if ((int)blockIdx.x < sp.first_unit) {
-    tile_id = xcd_remap(blockIdx.x, sp.first_unit);
-  } else {
-    unit = blockIdx.x - sp.first_unit;
-    tile_id = sp.first_unit + unit / sp.S;
-    seg = unit % sp.S;
-  }
-  const bool is_split = unit >= 0 && sp.S > 1;
-  const int kt_begin = is_split ? (int)((long)nk_total * seg / sp.S) : 0;
-  const int kt_end = is_split ? (int)((long)nk_total * (seg + 1) / sp.S) : nk_total;
+  int tile_id, seg, unit, kt_begin, kt_end;
+  const bool is_split = split_unit_of_block(sp, blockIdx.x, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
   // tile id -> (m, n): GROUP_M-row supertiles so concurrently running tiles share A / W panels in L2
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * p.tiles_n;
@@ -255,46 +239,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, g8:
 
   // ---- split-K fix-up: publish the partial tile, last arriver reduces (placement-independent agent-scope
   //      release/acquire; the slab is a per-lane register image, so the reduce is a plain elementwise add)
-  if (is_split) {
-    float4* slab = (float4*)(sp.slabs + (size_t)unit * SLAB_FLOATS);
-#pragma unroll
-    for (int blk = 0; blk < 8; ++blk)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x16& a = acc[blk >> 1][blk & 1];
-        slab[((wave * 8 + blk) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int* flag = (int*)smem;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *flag = __hip_atomic_fetch_add(sp.counters + (tile_id - sp.first_unit), 1, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    const int ticket = *flag;
-    if (ticket != sp.S - 1) return;  // not the last arriver: done
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    const int unit0 = unit - seg;
-    for (int s = 0; s < sp.S; ++s) {
-      if (s == seg) continue;
-      const float4* other = (const float4*)(sp.slabs + (size_t)(unit0 + s) * SLAB_FLOATS);
-#pragma unroll
-      for (int blk = 0; blk < 8; ++blk)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = other[((wave * 8 + blk) * 4 + q) * 64 + lane];
-          f32x16& a = acc[blk >> 1][blk & 1];
-          a[4 * q] += v.x;
-          a[4 * q + 1] += v.y;
-          a[4 * q + 2] += v.z;
-          a[4 * q + 3] += v.w;
-        }
-    }
-  }
+  if (is_split && !split_k_reduce(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
 
   store_tile<F16, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
 }
@@ -310,7 +255,7 @@ static int g_num_cus = 0;
 using namespace rtv;
 
 extern "C" size_t rtv_gemm_workspace_bytes(void) {
-  return (size_t)g8::MAX_SPLIT_UNITS * g8::SLAB_FLOATS * 4 + (size_t)g8::MAX_SPLIT_UNITS * 4 + 256;
+  return (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4 + (size_t)SPLIT_MAX_UNITS * 4 + 256;
 }
 
 extern "C" int rtv_gemm_set_workspace(void* ptr, size_t bytes) {
@@ -323,12 +268,41 @@ extern "C" int rtv_gemm_set_workspace(void* ptr, size_t bytes) {
   if (((uintptr_t)ptr) & 255) return set_error(-1, "gemm_set_workspace: pointer must be 256-byte aligned");
   if (bytes < rtv_gemm_workspace_bytes()) return set_error(-1, "gemm_set_workspace: too small (rtv_gemm_workspace_bytes)");
   g_slabs = (float*)ptr;
-  g_counters = (int*)((char*)ptr + (size_t)g8::MAX_SPLIT_UNITS * g8::SLAB_FLOATS * 4);
-  g_ws_units = g8::MAX_SPLIT_UNITS;
+  g_counters = (int*)((char*)ptr + (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4);
+  g_ws_units = SPLIT_MAX_UNITS;
   return 0;
 }
 
 namespace rtv {
+
+int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream) {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+      return set_error(-1, "gemm: cannot query the device");
+    g_num_cus = prop.multiProcessorCount;
+  }
+  const int G = g_num_cus;
+  *sp = SplitArgs{T, 1, nullptr, nullptr};
+  *grid = T;
+  const int R = T % G;
+  if (allow_split && g_slabs && T > G && R > 0) {
+    int S = G / R;                 // the split units of the partial round still fit one round
+    if (S > 8) S = 8;
+    if (S > nk / 4) S = nk / 4;    // keep >= 4 K-tiles per segment
+    if (S >= 2 && (size_t)R * S <= g_ws_units) {
+      sp->first_unit = T - R;
+      sp->S = S;
+      sp->slabs = g_slabs;
+      sp->counters = g_counters;
+      *grid = (T - R) + R * S;
+      if (hipMemsetAsync(g_counters, 0, (size_t)R * sizeof(int), stream) != hipSuccess)
+        return set_error(-1, "gemm: split-K counter memset failed");
+    }
+  }
+  return 0;
+}
 
 template <bool F16, int NL>
 static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
@@ -341,31 +315,9 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
     if (e != hipSuccess) return set_error(e, "gemm8: hipFuncSetAttribute");
     attr_set = true;
   }
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return set_error(-1, "gemm8: cannot query the device");
-    g_num_cus = prop.multiProcessorCount;
-  }
-  const int T = p.tiles_m * p.tiles_n, G = g_num_cus, nk = p.K / g8::BK;
-  g8::SplitArgs sp{T, 1, nullptr, nullptr};
-  int grid = T;
-  const int R = T % G;
-  if (allow_split && g_slabs && T > G && R > 0) {
-    int S = G / R;                 // the split units of the partial round still fit one round
-    if (S > 8) S = 8;
-    if (S > nk / 4) S = nk / 4;    // keep >= 4 K-tiles per segment
-    if (S >= 2 && (size_t)R * S <= g_ws_units) {
-      sp.first_unit = T - R;
-      sp.S = S;
-      sp.slabs = g_slabs;
-      sp.counters = g_counters;
-      grid = (T - R) + R * S;
-      if (hipMemsetAsync(g_counters, 0, (size_t)R * sizeof(int), stream) != hipSuccess)
-        return set_error(-1, "gemm8: counter memset failed");
-    }
-  }
+  SplitArgs sp;
+  int grid = 0;
+  if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8::BK, allow_split, &sp, &grid, stream)) return st;
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8::LDS_BYTES, stream, p, sp);
   return check_launch("gemm8");

@@ -1,0 +1,90 @@
+// In-launch split-K of the last, partial round of 256x256 output tiles (shared by gemm8.hip and gemm9.hip).
+//
+// T tiles on G CUs run as floor(T/G) full rounds plus R = T % G tiles; those R tiles would keep the chip at R/G
+// occupancy for a whole tile time.  Instead each of them is cut along K into S segments ("units", S = min(8, G/R)),
+// so the tail round runs R*S workgroups for 1/S of a tile time.  Partial accumulators go to an fp32 slab in a
+// caller-provided workspace (rtv_gemm_set_workspace); the last arriver of a tile (agent-scope release / acquire around
+// an arrival counter, no spinning) adds the other slabs to its registers and runs the fused epilogue.
+#pragma once
+#include "rtv_common.h"
+
+namespace rtv {
+
+constexpr int SPLIT_SLAB_FLOATS = 256 * 256;  // fp32 partial tile (256 KiB)
+constexpr int SPLIT_MAX_UNITS = 256;
+
+struct SplitArgs {
+  int first_unit;   // block ids >= first_unit are split units; full tiles before
+  int S;            // K segments per split tile (1 = no splitting)
+  float* slabs;     // [units][SPLIT_SLAB_FLOATS]
+  int* counters;    // [split tiles], zeroed by a memset node before the launch
+};
+
+// host: decide the split for T tiles of nk K-tiles each (defined in gemm8.hip, which owns the workspace pointers).
+// Fills *sp / *grid; enqueues the counter memset on `stream` when splitting.  Returns 0 or an error status.
+int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream);
+
+// device: block id -> (tile, K segment).  Returns true when this workgroup is a split unit.
+__device__ __forceinline__ bool split_unit_of_block(const SplitArgs& sp, int bid, int nk_total, int* tile_id, int* unit,
+                                                    int* seg, int* kt_begin, int* kt_end) {
+  *seg = 0;
+  *unit = -1;
+  if (bid < sp.first_unit) {
+    *tile_id = xcd_remap(bid, sp.first_unit);
+  } else {
+    *unit = bid - sp.first_unit;
+    *tile_id = sp.first_unit + *unit / sp.S;
+    *seg = *unit % sp.S;
+  }
+  const bool is_split = *unit >= 0 && sp.S > 1;
+  *kt_begin = is_split ? (int)((long)nk_total * *seg / sp.S) : 0;
+  *kt_end = is_split ? (int)((long)nk_total * (*seg + 1) / sp.S) : nk_total;
+  return is_split;
+}
+
+// device: publish this unit's partial 128x64-per-wave accumulators; the last arriver of the tile returns true with
+// the full sum in `acc` (placement-independent: the slab is a per-lane register image, the reduce is elementwise).
+// `smem` needs 4 free bytes at offset 0 (the K loop is over).  8 waves, acc = [4][2] blocks of 32x32 per wave.
+__device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[4][2], const SplitArgs& sp, int unit, int seg, int tile_id,
+                                               char* smem, int tid, int wave, int lane) {
+  float4* slab = (float4*)(sp.slabs + (size_t)unit * SPLIT_SLAB_FLOATS);
+#pragma unroll
+  for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x16& a = acc[blk >> 1][blk & 1];
+      slab[((wave * 8 + blk) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = (int*)smem;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    *flag = __hip_atomic_fetch_add(sp.counters + (tile_id - sp.first_unit), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int ticket = *flag;
+  if (ticket != sp.S - 1) return false;  // not the last arriver: done
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  const int unit0 = unit - seg;
+  for (int s = 0; s < sp.S; ++s) {
+    if (s == seg) continue;
+    const float4* other = (const float4*)(sp.slabs + (size_t)(unit0 + s) * SPLIT_SLAB_FLOATS);
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = other[((wave * 8 + blk) * 4 + q) * 64 + lane];
+        f32x16& a = acc[blk >> 1][blk & 1];
+        a[4 * q] += v.x;
+        a[4 * q + 1] += v.y;
+        a[4 * q + 2] += v.z;
+        a[4 * q + 3] += v.w;
+      }
+  }
+  return true;
+}
+
+}  // namespace rtv
