@@ -141,7 +141,13 @@ def main():
     wr = WanDiffusionWrapper(model, timestep_shift=5.0)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
                                    generator=wr)
-    vae = None if args.no_vae else VAEDecoderWrapper(dev).init_random_weights(seed=1)
+    if args.no_vae:
+        vae = None
+    elif use_cp:   # row-sharded decode: every rank decodes one horizontal stripe, one all-gather of pixels per block
+        from realtime_video_amd.parallel import ShardedVAEDecoder
+        vae = ShardedVAEDecoder(model.context_parallel, dev).init_random_weights(seed=1)
+    else:
+        vae = VAEDecoderWrapper(dev).init_random_weights(seed=1)
     vae_enc = None if args.no_vae else VAEEncoderWrapper(device=dev).init_random_weights(seed=2)
     keep_first = bool(args.no_vae or args.keep_first_frame)   # reference default: False = re-encode the first context frame every block
     g = torch.Generator(device=dev).manual_seed(42)
@@ -209,8 +215,9 @@ def main():
                     "frame through the streaming VAE encoder (release_server.py:572-575); warm-up >= 2 blocks puts the timed "
                     "blocks in that steady state",
             "parallelism": "single GPU" if world == 1 else (
-                f"cp{world}: one stream, token axis sharded {world}-way, K/V all-gather per layer over RCCL, VAE decode "
-                f"replicated on every rank" if use_cp else f"{world} independent replicas"),
+                f"cp{world}: one stream, token axis sharded {world}-way, K/V all-gather per layer over RCCL; VAE decode "
+                f"sharded by output rows ({world} stripes + conv halos, one pixel all-gather per block), first-frame "
+                f"re-encode replicated" if use_cp else f"{world} independent replicas"),
             "dit_ms_per_forward": (prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
                                    + prof["misc"]["ms"]) / (args.steps * fwd_per_block),
             "vae_ms_per_block": prof["conv"]["ms"] / args.steps,

@@ -214,6 +214,13 @@ enum { RTV_CONV_NONE = 0, RTV_CONV_UPSAMPLE2X = 1, RTV_CONV_DOWN2X = 2, RTV_CONV
 int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
                 void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                 int resample, int n_split, const void* zeros, rtv_stream_t stream);
+/* Row-window form of RTV_CONV_UPSAMPLE2X for the spatially sharded decode: the output buffer holds image rows
+ * [y_out0, y_out0+H) (output resolution), the input buffer in_rows rows starting at image row y_in0 (input resolution);
+ * img_rows = image height at output resolution (taps outside the IMAGE read zeros). */
+int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
+                    void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                    int resample, int n_split, const void* zeros, int y_out0, int y_in0, int in_rows, int img_rows,
+                    rtv_stream_t stream);
 /* RMS_norm over channels (+SiLU) on channels-last pixels (wan/modules/vae.py:39-54): C in {96,192,384}. */
 int rtv_rmsnorm_silu_cl(const void* x, void* out, const void* gamma, int C, int64_t npix, int apply_silu,
                         rtv_stream_t stream);
@@ -245,6 +252,15 @@ int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, i
 /* z: fp16 [T][16][h][w] latents; pixels: float32 [T'][3][8h][8w] in [-1,1], T' = 4T (4T-3 when first). */
 int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first,
                    void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
+/* Spatially sharded decode (multi-GPU, SURVEY 8e "VAE decode: shard by output rows with halo"): produce only pixel rows
+ * [row0, row1) of every frame -> pixels float32 [T'][3][row1-row0][8w], bit-identical to those rows of rtv_vae_decode.
+ * Stage 0 (latent resolution, global mid-block attention) runs on the whole image; stages 1-3 run on row windows with
+ * halo rows (1 per 3x3 conv between the window and the wanted rows).  Arena / cache-slot geometry depend on the rows. */
+size_t rtv_vae_arena_bytes_rows(int h, int w, int row0, int row1);
+int rtv_vae_cache_slot_rows(int h, int w, int row0, int row1, int slot, size_t* offset, int* C, int* H, int* W,
+                            int* first_row);
+int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, int row0, int row1,
+                        void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
 
 /* Streaming VAE encoder: VAEEncoderWrapper.forward (demo_utils/vae_block3.py:116-175) over Encoder3d
  * (wan/modules/vae.py:254-345; _video_vae config :591-598: dim 96, z_dim 16, temperal_downsample F,T,T).

@@ -187,8 +187,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
   float l_run = 0.f;     // this lane's partial row sum
   const float c = p.scale_log2e;
   const f32x2 c2 = {c, c};
-  // Lazy rescaling: O and l are only rescaled when some row's maximum has grown by more than 2^8 since the last
-  // rescale (a wave-uniform, rare branch after the first tiles).  The result is the same softmax — any reference
+  // Lazy rescaling: O and l of a row are only rescaled when that row's maximum has grown by more than 2^8 since its
+  // last rescale (a rare branch after the first tiles).  The result is the same softmax — any reference
   // point cancels in O/l — with P <= 256 in the 16-bit MFMA operand and f32 accumulators.
   constexpr float RESCALE_SLACK = 8.f;
 
@@ -238,9 +238,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_cand = fmaxf(m_run, mx * c);
-    if (__builtin_amdgcn_ballot_w64(m_cand - m_run > RESCALE_SLACK) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_cand);
-      m_run = m_cand;
+    const bool need = m_cand - m_run > RESCALE_SLACK;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      // the branch is wave-uniform, the decision per row: rows that do not need it multiply by exp2(0) = 1 exactly, so a
+      // row's arithmetic never depends on which other rows share its wave (token-sharded == unsharded, bit for bit)
+      const float m_new = need ? m_cand : m_run;
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
       l_run *= alpha;
 #pragma unroll
       for (int db = 0; db < 4; ++db)

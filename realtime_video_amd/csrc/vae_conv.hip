@@ -38,6 +38,9 @@ struct ConvParams {
   int sy, st;       // spatial / temporal stride of the output grid over the input (1 or 2)
   int pad_h, pad_w; // low-side zero padding (kh/2 for 'same' convs, 0 for the stride-2 downsample: its ZeroPad2d is high-side)
   int limH, limW;   // taps outside [0,limH) x [0,limW) read zeros (input dims, or output dims when ups)
+  int y_out0, y_in0; // row windows (spatially sharded decode): output row py is image row y_out0 + py, input buffer row 0
+                     // is image row y_in0 (in input resolution); limH is then the IMAGE height
+  int in_rows;       // rows held by the input buffer
   int n_split;      // >0: output channel n -> frame 2t + n / n_split, channel n % n_split
   int M;            // T*H*W
   int tiles_m, tiles_n;
@@ -94,10 +97,11 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
     const int dx = r2 - (r2 / p.kw) * p.kw - p.pad_w;
 #pragma unroll
     for (int i = 0; i < Cfg::A_INST; ++i) {
-      const int yy = py[i] * p.sy + dy, xx = px[i] * p.sy + dx;
+      const int yy = p.y_out0 + py[i] * p.sy + dy, xx = px[i] * p.sy + dx;
       const bool ok = (yy >= 0) & (yy < p.limH) & (xx >= 0) & (xx < p.limW);
       const int ti = pt[i] * p.st + dt;
-      const size_t off = ((size_t)(ti * p.inH + (yy >> p.ups)) * p.inW + (xx >> p.ups)) * p.Cin + c0 + a_chunk[i];
+      const int sy_ = min(max((yy >> p.ups) - p.y_in0, 0), p.in_rows - 1);
+      const size_t off = ((size_t)(ti * p.inH + sy_) * p.inW + (xx >> p.ups)) * p.Cin + c0 + a_chunk[i];
       const uint16_t* src = ok ? p.in + off : p.zeros;
       dma16(src, sA + (wave * Cfg::A_INST + i) * 1024);
     }
@@ -206,15 +210,31 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
 
 using namespace rtv;
 
+/* Row-window variant (spatially sharded decode): the output buffer holds image rows [y_out0, y_out0 + H), the input
+ * buffer `in_rows` rows starting at image row y_in0 (input resolution), the image has img_rows rows at OUTPUT resolution.
+ * Only meaningful with RTV_CONV_UPSAMPLE2X (the stage transition); other modes treat the window as the image. */
+extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
+                               void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                               int resample, int n_split, const void* zeros, int y_out0, int y_in0, int in_rows,
+                               int img_rows, rtv_stream_t stream);
+
 /* Standalone C entry (used by the tests): one convolution launch. */
 extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
                            void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                            int resample, int n_split, const void* zeros, rtv_stream_t stream) {
+  return rtv_conv_cl_win(in, w, bias, residual, res_ld, out, out_ld, T, H, W, Cin, Cout, kt, kh, kw, resample, n_split,
+                         zeros, 0, 0, -1, -1, stream);
+}
+
+extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
+                               void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                               int resample, int n_split, const void* zeros, int y_out0, int y_in0, int in_rows,
+                               int img_rows, rtv_stream_t stream) {
   if (!in || !w || !out || !zeros) return set_error(-1, "conv: null pointer");
   if ((kt != 1 && kt != 3) || (kh != 1 && kh != 3) || kh != kw) return set_error(-1, "conv: kernel must be 1 or 3 per axis");
   if (resample < 0 || resample > 3) return set_error(-1, "conv: resample must be 0..3");
   const int ups = resample == RTV_CONV_UPSAMPLE2X;
-  if (ups && ((H | W) & 1)) return set_error(-1, "conv: upsampled output dims must be even");
+  if (ups && ((W & 1) || (in_rows < 0 && (H & 1)))) return set_error(-1, "conv: upsampled output dims must be even");
   if (resample == RTV_CONV_DOWN2X && (kt != 1 || kh != 3)) return set_error(-1, "conv: the stride-2 downsample is a 1x3x3 conv");
   if (resample == RTV_CONV_TIME_DOWN2X && (kt != 3 || kh != 1)) return set_error(-1, "conv: the stride-2 time conv is 3x1x1");
   if (resample != RTV_CONV_NONE && resample != RTV_CONV_UPSAMPLE2X && n_split) return set_error(-1, "conv: n_split with a strided conv");
@@ -238,6 +258,18 @@ extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, cons
   p.pad_w = resample == RTV_CONV_DOWN2X ? 0 : kw >> 1;
   p.limH = ups ? H : p.inH;
   p.limW = ups ? W : p.inW;
+  p.y_out0 = p.y_in0 = 0;
+  p.in_rows = p.inH;
+  if (in_rows >= 0) {  // row-window call
+    if (!ups) return set_error(-1, "conv: row windows are for the upsampling stage transition");
+    if (in_rows <= 0 || img_rows <= 0 || y_out0 < 0 || y_in0 < 0 || y_out0 + H > img_rows)
+      return set_error(-1, "conv: bad row window");
+    p.y_out0 = y_out0;
+    p.y_in0 = y_in0;
+    p.in_rows = in_rows;
+    p.inH = in_rows;      // slice stride of the input buffer
+    p.limH = img_rows;
+  }
   p.Cin = Cin;
   p.Cout = Cout;
   p.kt = kt;

@@ -14,18 +14,19 @@ int launch_conv(const ConvParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------ RMS_norm (+SiLU), channels-last
 // F.normalize(x, dim=C) * sqrt(C) * gamma  (wan/modules/vae.py:39-54) followed by nn.SiLU.
-// 256 threads x 3 chunks of 8 channels = 768 chunks per block = 768/(C/8) whole pixels; the per-pixel
-// sum of squares is accumulated with LDS float atomics so every global access stays a coalesced 16 B.
+// 256 threads x 3 chunks of 8 channels = 768 chunks per block = 768/(C/8) whole pixels; every global access stays a
+// coalesced 16 B.  The per-pixel sum of squares is reduced through LDS in a FIXED order (one thread per pixel adds the
+// pixel's chunk partials in sequence), so the result does not depend on scheduling: the spatially sharded decode must
+// reproduce the unsharded one bit for bit.
 constexpr int RN_CHUNKS = 3;
 __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ out,
                                                              const f16_t* __restrict__ gamma, int C,
                                                              int64_t npix, int apply_silu) {
   __shared__ float ssq[64];
+  __shared__ float part[256 * RN_CHUNKS];
   const int G = C >> 3;               // chunks per pixel (12 / 24 / 48)
   const int ppb = (256 * RN_CHUNKS) / G;  // pixels per block
   const int64_t pix0 = (int64_t)blockIdx.x * ppb;
-  if (threadIdx.x < 64) ssq[threadIdx.x] = 0.f;
-  __syncthreads();
   float v[RN_CHUNKS][8];
   int lp[RN_CHUNKS];
 #pragma unroll
@@ -42,8 +43,14 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_cl_kernel(const f16_t* __res
         unpack_f16x2(u, v[i][2 * j], v[i][2 * j + 1]);
         s += v[i][2 * j] * v[i][2 * j] + v[i][2 * j + 1] * v[i][2 * j + 1];
       }
-      atomicAdd(&ssq[lp[i]], s);
     }
+    part[c] = s;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < ppb) {
+    float t = 0.f;
+    for (int k = 0; k < G; ++k) t += part[threadIdx.x * G + k];
+    ssq[threadIdx.x] = t;
   }
   __syncthreads();
   const float sqrtC = sqrtf((float)C);
@@ -174,12 +181,13 @@ __global__ void vae_prep_kernel(const f16_t* __restrict__ z, int t, int hw, cons
   dst[3] = o[3];
 }
 
-// head output [T][H][W][8] f16 (3 real channels) -> pixels f32 [T][3][H][W], clamped to [-1, 1]
-__global__ void vae_final_kernel(const f16_t* __restrict__ in, float* __restrict__ out, int T, int64_t hw) {
+// head output [T][Hin][W][8] f16 (3 real channels; rows skip .. skip + rows of it) -> pixels f32 [T][3][rows][W] in [-1, 1]
+__global__ void vae_final_kernel(const f16_t* __restrict__ in, float* __restrict__ out, int T, int64_t hw, int64_t in_hw,
+                                 int64_t skip_px) {
   const int64_t total = (int64_t)T * hw;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / hw, p = i - t * hw;
-    u32x2 raw = *(const u32x2*)(in + i * 8);
+    u32x2 raw = *(const u32x2*)(in + (t * in_hw + skip_px + p) * 8);
     const uint32_t u0 = raw[0], u1 = raw[1];
     float c0, c1, c2, c3;
     unpack_f16x2(u0, c0, c1);
@@ -232,6 +240,36 @@ struct Stage {
   int H, W;
 };
 
+// Row windows of a spatially sharded decode (one rank produces pixel rows [r0, r1)): stage s (resolution h << s) only
+// holds image rows [a[s], b[s]).  Every conv treats its window as the image (zero padding at the window edges), which
+// is wrong by one more row per 3x3 conv at edges that are not image borders, so the windows carry that many halo rows:
+// 7 at full resolution (6 ResidualBlock convs + head), 6 per earlier stage plus the one row the stage-transition conv
+// reads beyond its output.  Stage 0 (conv1, the global mid-block attention, 4 % of the FLOPs) is never windowed.
+struct RowPlan {
+  int a[4], b[4];
+  int r0, r1;
+};
+
+static int make_plan(int h, int r0, int r1, RowPlan* P) {
+  const int H3 = h << 3;
+  if (r0 < 0 || r1 > H3 || r0 >= r1) return set_error(-1, "vae_decode: bad pixel row range");
+  P->r0 = r0;
+  P->r1 = r1;
+  P->a[3] = r0 - 7 > 0 ? r0 - 7 : 0;
+  P->b[3] = r1 + 7 < H3 ? r1 + 7 : H3;
+  for (int s = 2; s >= 1; --s) {
+    const int Hs = h << s;
+    int lo = (P->a[s + 1] - 1) >> 1, hi = (P->b[s + 1] >> 1) + 1;  // source rows of the upsampled taps a-1 .. b
+    if (lo < 0) lo = 0;
+    if (hi > Hs) hi = Hs;
+    P->a[s] = lo - 6 > 0 ? lo - 6 : 0;
+    P->b[s] = hi + 6 < Hs ? hi + 6 : Hs;
+  }
+  P->a[0] = 0;
+  P->b[0] = h;
+  return 0;
+}
+
 struct VaeLayout {
   // persistent: 32 concat buffers (2 cache slices + Tmax new slices each)
   size_t cat_off[32];
@@ -245,7 +283,7 @@ struct VaeLayout {
 };
 
 // concat-buffer table in execution order: (channels, stage, Tmax)
-static void build_layout(int h, int w, VaeLayout* L) {
+static void build_layout(int h, int w, const RowPlan& plan, VaeLayout* L) {
   const int C[32] = {32, 384, 384, 384, 384,            // conv1, mid0.a, mid0.b, mid2.a, mid2.b
                      384, 384, 384, 384, 384, 384, 384,   // up0 x3 (a,b), time_conv0
                      192, 384, 384, 384, 384, 384, 384,   // up1: (192->384) a, b, then 384 x4, time_conv1
@@ -261,7 +299,7 @@ static void build_layout(int h, int w, VaeLayout* L) {
   };
   for (int i = 0; i < 32; ++i) {
     const int s = S[i];
-    const size_t hw = (size_t)(h << s) * (w << s);
+    const size_t hw = (size_t)(plan.b[s] - plan.a[s]) * (w << s);
     L->cat_C[i] = C[i];
     L->cat_stage[i] = s;
     L->cat_T[i] = Tm[s];
@@ -271,14 +309,14 @@ static void build_layout(int h, int w, VaeLayout* L) {
   size_t amax = 0;
   const int actC[4] = {768, 768, 384, 192};  // widest tensor living at each stage (time_conv output counted at source res)
   for (int s = 0; s < 4; ++s) {
-    size_t hw = (size_t)(h << s) * (w << s);
+    size_t hw = (size_t)(plan.b[s] - plan.a[s]) * (w << s);
     size_t b = (size_t)Tm[s] * hw * actC[s] * 2;
     if (b > amax) amax = b;
-  }
-  {
-    size_t hw3 = (size_t)(h << 3) * (w << 3);
-    size_t b = (size_t)4 * hw3 * 96 * 2;
-    if (b > amax) amax = b;
+    if (s < 3) {  // the stage-transition conv writes [T][rows of stage s+1][C/2]
+      size_t hw1 = (size_t)(plan.b[s + 1] - plan.a[s + 1]) * (w << (s + 1));
+      size_t b1 = (size_t)Tm[s + 1] * hw1 * (actC[s] / 4) * 2;
+      if (b1 > amax) amax = b1;
+    }
   }
   for (int i = 0; i < 4; ++i) L->act_off[i] = take(amax);
   const size_t P = (size_t)h * w;
@@ -290,31 +328,45 @@ static void build_layout(int h, int w, VaeLayout* L) {
   L->vt_off = take((size_t)384 * L->ldp * 2);
   L->o_off = take(P * 384 * 2);
   L->xn_off = take(P * 384 * 2);
-  L->head_off = take((size_t)4 * (h << 3) * (w << 3) * 8 * 2);
+  L->head_off = take((size_t)4 * (plan.b[3] - plan.a[3]) * (w << 3) * 8 * 2);
   L->zeros_off = take(256);
   L->total = off + 256;
 }
 
 }  // namespace
 
-extern "C" size_t rtv_vae_arena_bytes(int h, int w) {
+extern "C" size_t rtv_vae_arena_bytes_rows(int h, int w, int row0, int row1) {
   if (h <= 0 || w <= 0) return 0;
+  RowPlan P;
+  if (make_plan(h, row0, row1, &P)) return 0;
   VaeLayout L;
-  build_layout(h, w, &L);
+  build_layout(h, w, P, &L);
   return L.total;
 }
 
+extern "C" size_t rtv_vae_arena_bytes(int h, int w) { return rtv_vae_arena_bytes_rows(h, w, 0, h << 3); }
+
 /* byte offset + slice geometry of feature-cache slot i (0..31) inside the arena: the two cached slices
  * are the first two [H][W][C] slices of the conv's concat buffer. */
-extern "C" int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, int* W) {
+extern "C" int rtv_vae_cache_slot_rows(int h, int w, int row0, int row1, int slot, size_t* offset, int* C, int* H,
+                                       int* W, int* first_row) {
   if (slot < 0 || slot >= 32) return set_error(-1, "vae_cache_slot: slot out of range");
+  RowPlan P;
+  RTV_TRY(make_plan(h, row0, row1, &P));
   VaeLayout L;
-  build_layout(h, w, &L);
+  build_layout(h, w, P, &L);
+  const int s = L.cat_stage[slot];
   *offset = L.cat_off[slot];
   *C = L.cat_C[slot];
-  *H = h << L.cat_stage[slot];
-  *W = w << L.cat_stage[slot];
+  *H = P.b[s] - P.a[s];
+  *W = w << s;
+  *first_row = P.a[s];
   return 0;
+}
+
+extern "C" int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, int* W) {
+  int first_row = 0;
+  return rtv_vae_cache_slot_rows(h, w, 0, h << 3, slot, offset, C, H, W, &first_row);
 }
 
 namespace {
@@ -395,18 +447,29 @@ static int mid_attention(Ctx& c, const rtv_vae_attn& a, const uint16_t* x, uint1
 
 }  // namespace
 
-extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, void* arena,
-                              size_t arena_bytes, void* pixels, rtv_stream_t stream_) {
+extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
+                               void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
+                               int resample, int n_split, const void* zeros, int y_out0, int y_in0, int in_rows,
+                               int img_rows, rtv_stream_t stream);
+
+/* Decode producing only pixel rows [row0, row1) (a horizontal stripe of every frame): the spatially sharded decode of
+ * the context-parallel path.  Stage 0 runs on the whole latent image; stages 1-3 on the row windows of make_plan().
+ * pixels: float32 [T'][3][row1-row0][8w].  row0 = 0, row1 = 8h is the plain decode. */
+extern "C" int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, int row0,
+                                   int row1, void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream_) {
   if (!w || !z || !arena || !pixels) return set_error(-1, "vae_decode: null argument");
   if (T <= 0) return 0;
   if ((h * wd) % 8) return set_error(-1, "vae_decode: h*w must be a multiple of 8");
   if (((uintptr_t)arena) & 255) return set_error(-1, "vae_decode: arena must be 256-byte aligned");
+  RowPlan P;
+  RTV_TRY(make_plan(h, row0, row1, &P));
   VaeLayout L;
-  build_layout(h, wd, &L);
+  build_layout(h, wd, P, &L);
   if (arena_bytes < L.total) return set_error(-1, "vae_decode: arena too small (see rtv_vae_arena_bytes)");
   hipStream_t stream = (hipStream_t)stream_;
   Ctx c{(char*)arena, &L, h, wd, stream, 0};
-  const int64_t HW8 = (int64_t)(h * 8) * (wd * 8);
+  const int W8 = wd * 8;
+  const int64_t out_hw = (int64_t)(row1 - row0) * W8;
   int out_frame = 0;
   // V^T pad columns (K padding of the P.V GEMM) must be zero
   if (L.ldp != h * wd)
@@ -415,7 +478,7 @@ extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, in
 
   for (int f = 0; f < T; ++f) {
     const bool is_first = first && f == 0;
-    int H = h, W = wd, Tn = 1;
+    int H = h, W = wd, Tn = 1;  // H = rows of the current stage's window
     uint16_t *a0 = c.act(0), *a1 = c.act(1), *a2 = c.act(2), *a3 = c.act(3);
     // conv2 (1x1x1, 16->16) + de-normalisation, written into conv1's concat buffer (32-channel padded)
     {
@@ -472,11 +535,13 @@ extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, in
         }
         ci += 1;
       }
-      // nearest 2x + Conv2d 3x3 (cout -> cout/2), per frame
-      RTV_TRY(rtv_conv_cl(x, w->resample[s].w, w->resample[s].b, nullptr, 0, free_[0], cout / 2, Tn, 2 * H, 2 * W, cout,
-                          cout / 2, 1, 3, 3, 1, 0, c.zeros(), stream));
+      // nearest 2x + Conv2d 3x3 (cout -> cout/2), per frame: produces the row window of the next stage from this one's
+      const int Hn = P.b[s + 1] - P.a[s + 1];
+      RTV_TRY(rtv_conv_cl_win(x, w->resample[s].w, w->resample[s].b, nullptr, 0, free_[0], cout / 2, Tn, Hn, 2 * W, cout,
+                              cout / 2, 1, 3, 3, RTV_CONV_UPSAMPLE2X, 0, c.zeros(), P.a[s + 1], P.a[s], H, h << (s + 1),
+                              stream));
       x = free_[0];
-      H *= 2;
+      H = Hn;
       W *= 2;
     }
     // head: RMS_norm, SiLU, conv 96 -> 3 (filters padded to 8)
@@ -486,12 +551,18 @@ extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, in
       uint16_t* ho = (uint16_t*)((char*)arena + L.head_off);
       RTV_TRY(cached_conv3(c, 31, Tn, H, W, 96, w->head, 8, nullptr, ho, 8));
       hipLaunchKernelGGL(vae_final_kernel, dim3(2048), dim3(256), 0, stream, (const f16_t*)ho,
-                         (float*)pixels + (size_t)out_frame * 3 * HW8, Tn, HW8);
+                         (float*)pixels + (size_t)out_frame * 3 * out_hw, Tn, out_hw, (int64_t)H * W,
+                         (int64_t)(row0 - P.a[3]) * W);
       RTV_TRY(check_launch("vae_final"));
       out_frame += Tn;
     }
   }
   return 0;
+}
+
+extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, void* arena,
+                              size_t arena_bytes, void* pixels, rtv_stream_t stream) {
+  return rtv_vae_decode_rows(w, z, T, h, wd, first, 0, h << 3, arena, arena_bytes, pixels, stream);
 }
 
 // ====================================================================================== streaming encoder

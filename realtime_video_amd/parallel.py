@@ -96,3 +96,47 @@ class SimulatedContextParallel:
 
     def gather_kv(self, k, v, row0, M):
         return None
+
+
+class ShardedVAEDecoder:
+    """Spatially sharded streaming VAE decode for the context-parallel path ("VAE decode: shard by output
+    rows with halo"): rank r decodes the r-th horizontal stripe of every frame (`rtv_vae_decode_rows`: stage 0 and the
+    global mid-block attention replicated, stages 1-3 on row windows with conv halos) and ONE all-gather per block
+    returns whole frames on every rank (they feed the first-frame re-encode and the frame callback).  Same call
+    contract as VAEDecoderWrapper: `pixels, cache = decoder(latents, *cache)`; the stripes are bit-identical to the
+    corresponding rows of the unsharded decode."""
+
+    def __init__(self, cp, device="cuda"):
+        from .vae_decoder import VAEDecoderWrapper
+        self.cp = cp
+        self.inner = VAEDecoderWrapper(device, row_shard=(cp.rank, cp.world))
+
+    def load_state_dict(self, sd, strict=True):
+        return self.inner.load_state_dict(sd, strict)
+
+    def init_random_weights(self, seed=0):
+        self.inner.init_random_weights(seed)
+        return self
+
+    def eval(self):
+        return self
+
+    def forward(self, z, *feat_cache):
+        stripe, cache = self.inner(z, *feat_cache)          # [1, T', 3, rows, W]
+        return gather_row_stripes(self.cp, stripe[0], 8 * z.shape[3]).unsqueeze(0), cache
+
+    __call__ = forward
+
+
+def gather_row_stripes(cp, stripe, H):
+    """stripe: [T, C, rows_r, W] = rows [H*r//n, H*(r+1)//n) of a [T, C, H, W] image stack on rank r -> full stack."""
+    n = cp.world
+    T, C, _, W = stripe.shape
+    bounds = [(H * r // n, H * (r + 1) // n) for r in range(n)]
+    rows_max = max(b - a for a, b in bounds)
+    buf = torch.zeros((n, T, C, rows_max, W), dtype=stripe.dtype, device=stripe.device)
+    buf[cp.rank, :, :, :stripe.shape[2]] = stripe
+    cp.all_gather_rows_(buf)
+    if all(b - a == rows_max for a, b in bounds):
+        return buf.permute(1, 2, 0, 3, 4).reshape(T, C, H, W)
+    return torch.cat([buf[r, :, :, :b - a] for r, (a, b) in enumerate(bounds)], dim=2)

@@ -45,6 +45,10 @@ _lib.EXTRA_SIGNATURES.update({
                        c_vp, ctypes.c_size_t, c_vp, c_vp],
     "rtv_vae_cache_slot": [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t),
                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "rtv_conv_cl_win": [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int] + [ctypes.c_int] * 10 + [c_vp]
+                       + [ctypes.c_int] * 4 + [c_vp],
+    "rtv_vae_decode_rows": [ctypes.POINTER(_VaeWeights), c_vp] + [ctypes.c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp, c_vp],
+    "rtv_vae_cache_slot_rows": [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_size_t)] + [ctypes.POINTER(ctypes.c_int)] * 4,
 })
 
 MEAN = [-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
@@ -71,11 +75,23 @@ def pack_conv_weight(w, cin_pad=None, cout_pad=None):
 class VAEDecoderWrapper:
     z_dim = 16
 
-    def __init__(self, device="cuda"):
+    def __init__(self, device="cuda", row_shard=None):
+        """row_shard = (index, count): this instance decodes only the index-th of `count` horizontal stripes of every
+        frame (spatially sharded decode of the context-parallel path; realtime_video_amd.parallel.ShardedVAEDecoder
+        gathers the stripes).  None = whole frames, the reference behaviour."""
         self.device = torch.device(device)
         self._t = {}
         self._w = None
         self._arena_bytes = {}
+        self.row_shard = row_shard
+
+    def row_range(self, h):
+        """Pixel rows [r0, r1) this instance produces for latent height h."""
+        H = 8 * h
+        if self.row_shard is None:
+            return 0, H
+        i, n = self.row_shard
+        return H * i // n, H * (i + 1) // n
 
     def eval(self):
         return self
@@ -213,16 +229,20 @@ class VAEDecoderWrapper:
     # ------------------------------------------------------------------ arena / cache views
     def _new_arena(self, h, w):
         lib = _lib.load()
-        lib.rtv_vae_arena_bytes.restype = ctypes.c_size_t
-        lib.rtv_vae_arena_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
-        n = lib.rtv_vae_arena_bytes(h, w)
+        lib.rtv_vae_arena_bytes_rows.restype = ctypes.c_size_t
+        lib.rtv_vae_arena_bytes_rows.argtypes = [ctypes.c_int] * 4
+        n = lib.rtv_vae_arena_bytes_rows(h, w, *self.row_range(h))
+        if n == 0:
+            raise ValueError("VAE decoder: bad latent size / row range")
         return torch.zeros(n + 256, dtype=torch.uint8, device=self.device)
 
     def _cache_views(self, arena, base, h, w):
         views = [None] * 55
-        off, C, H, Wd = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        off, C, H, Wd, fr = ctypes.c_size_t(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        r0, r1 = self.row_range(h)
         for i in range(32):
-            _lib.call("rtv_vae_cache_slot", h, w, i, ctypes.byref(off), ctypes.byref(C), ctypes.byref(H), ctypes.byref(Wd))
+            _lib.call("rtv_vae_cache_slot_rows", h, w, r0, r1, i, ctypes.byref(off), ctypes.byref(C), ctypes.byref(H),
+                      ctypes.byref(Wd), ctypes.byref(fr))
             n = 2 * H.value * Wd.value * C.value
             start = base + off.value
             flat = arena[start:start + n * 2].view(torch.float16)
@@ -250,8 +270,9 @@ class VAEDecoderWrapper:
         else:
             arena, base = feat_cache[0]._rtv_arena
         n_out = 4 * T - 3 if first else 4 * T
-        pixels = torch.empty((n_out, 3, 8 * h, 8 * w), dtype=torch.float32, device=z.device)
-        _lib.call("rtv_vae_decode", ctypes.byref(self._w), c_vp(zz.data_ptr()), T, h, w, int(first),
+        r0, r1 = self.row_range(h)
+        pixels = torch.empty((n_out, 3, r1 - r0, 8 * w), dtype=torch.float32, device=z.device)
+        _lib.call("rtv_vae_decode_rows", ctypes.byref(self._w), c_vp(zz.data_ptr()), T, h, w, int(first), r0, r1,
                   c_vp(arena.data_ptr() + base), ctypes.c_size_t(arena.numel() - base), c_vp(pixels.data_ptr()),
                   c_vp(torch.cuda.current_stream().cuda_stream))
         cache = list(feat_cache) if not first else self._cache_views(arena, base, h, w)

@@ -138,3 +138,30 @@ def test_shard_rows():
     assert [shard_rows(4680, 2, r) for r in range(2)] == [(0, 2340), (2340, 2340)]
     with pytest.raises(ValueError):
         shard_rows(100, 8, 0)
+
+
+def _stripe_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from realtime_video_amd.parallel import gather_row_stripes
+        cp = ContextParallel()
+        out = {}
+        for H in (16, 15):   # even and uneven stripe heights
+            full = torch.arange(2 * 3 * H * 4, dtype=torch.float32).view(2, 3, H, 4)
+            r0, r1 = H * rank // world, H * (rank + 1) // world
+            out[H] = gather_row_stripes(cp, full[:, :, r0:r1].contiguous(), H)
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_row_stripes_world2():
+    """The pixel-stripe all-gather of the row-sharded VAE decode (parallel.ShardedVAEDecoder)."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_stripe_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for rank in range(world):
+        for H in (16, 15):
+            full = torch.arange(2 * 3 * H * 4, dtype=torch.float32).view(2, 3, H, 4)
+            assert torch.equal(ret[rank][H], full), (rank, H)

@@ -1,5 +1,5 @@
-"""Two real processes driving the context-parallel DiT path (ContextParallel + phase API + HIP kernels) on the
-MI355X.  The test box has ONE GPU, so both ranks share cuda:0 and the collective runs over gloo (staged
+"""Two real processes driving the context-parallel path (ContextParallel + phase API + row-sharded VAE decode + HIP
+kernels) on the MI355X.  The test box has ONE GPU, so both ranks share cuda:0 and the collective runs over gloo (staged
 through the host); on a multi-GPU node the identical code path runs over RCCL (bench.py --gpus N)."""
 import os
 import socket
@@ -26,6 +26,9 @@ def _run_session(cp):
     from realtime_video_amd.causal_model import CausalWanModel
     from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
     from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    from realtime_video_amd.parallel import ShardedVAEDecoder
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
     from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
     dev = "cuda:0"
     cfg = dict(TINY)
@@ -39,12 +42,25 @@ def _run_session(cp):
     g = torch.Generator().manual_seed(5)
     prompt = torch.zeros(1, 512, TEXT_DIM, dtype=torch.bfloat16)
     prompt[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
-    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(prompt.to(dev)))
-    sess = GenerationSession(GenerateParams(seed=3, num_blocks=2, num_denoising_steps=4, keep_first_frame=True),
+    # VAE: row-sharded decode + one all-gather of the stripes under context parallelism, whole frames otherwise; the
+    # first-frame re-encode (keep_first_frame=False, block 2) consumes the gathered pixels
+    dec = (ShardedVAEDecoder(cp, dev) if cp is not None else VAEDecoderWrapper(dev)).init_random_weights(seed=1)
+    enc = VAEEncoderWrapper(device=dev).init_random_weights(seed=2)
+    if os.environ.get("RTV_DBG_ENC"):
+        _enc, rec = enc, []
+
+        def enc(frames, cache, stream=False):   # noqa: F811
+            mu, c = _enc(frames, cache, stream=stream)
+            rec.append((frames.float().cpu(), mu.float().cpu()))
+            return mu, c
+        _run_session.rec = rec
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(prompt.to(dev)), vae_decoder=dec,
+                    vae_encoder=enc)
+    sess = GenerationSession(GenerateParams(seed=3, num_blocks=3, num_denoising_steps=4, keep_first_frame=False),
                              models, device=dev)
-    outs = [sess.generate_block().clone() for _ in range(2)]
+    outs = [sess.generate_block().clone() for _ in range(3)]
     torch.cuda.synchronize()
-    return [o.cpu() for o in outs], pipe.kv_cache1[1]["k"].cpu()
+    return [o.cpu() for o in outs] + [sess.all_latents.cpu()], pipe.kv_cache1[1]["k"].cpu()
 
 
 def _worker(rank, world, port, ret):
@@ -54,6 +70,8 @@ def _worker(rank, world, port, ret):
         from realtime_video_amd.parallel import ContextParallel
         outs, k = _run_session(ContextParallel())
         ret[rank] = (outs, k)
+        if os.environ.get("RTV_DBG_ENC"):
+            ret[f"enc{rank}"] = list(_run_session.rec)
     finally:
         dist.destroy_process_group()
 

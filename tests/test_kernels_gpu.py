@@ -301,3 +301,19 @@ def test_patchify_unpatchify(ops):
     tok = _randn(F_ * gh * gw, 64, seed=3)
     out = ops.unpatchify(tok, 16, F_, gh, gw)
     assert torch.equal(out.cpu(), wo.unpatchify(tok.cpu(), (F_, gh, gw)))
+
+
+def test_attention_rows_independent_of_wave_grouping(ops):
+    """Token sharding changes which query rows share a wave.  A row's result must not depend on it (context-parallel ==
+    unsharded, bit for bit): the lazy softmax rescale is decided per row.  Keys grow in magnitude along the sequence so
+    that rescales do fire after the first tiles."""
+    g = torch.Generator().manual_seed(11)
+    Lq, Lkv, H = 600, 1024, 2
+    q = (torch.randn(1, Lq, H, 128, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    ramp = torch.linspace(0.2, 6.0, Lkv).view(1, Lkv, 1, 1)
+    k = (torch.randn(1, Lkv, H, 128, generator=g) * ramp).to(torch.bfloat16).to(DEV)
+    v = torch.randn(1, Lkv, H, 128, generator=g).to(torch.bfloat16).to(DEV)
+    full = ops.attn_fwd(q, k, v)
+    for off in (4, 37, 300):
+        part = ops.attn_fwd(q[:, off:].contiguous(), k, v)
+        assert torch.equal(part, full[:, off:]), off

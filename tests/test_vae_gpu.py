@@ -219,3 +219,38 @@ def test_encoder_rejects_cpu_and_bad_chunks():
     mu, cache = enc(torch.zeros(1, 3, 1, 64, 96, dtype=torch.float16, device=DEV), [None] * 55)
     with pytest.raises(ValueError):   # non-stream continuation: the reference slices z[:, :, -3:1] here
         enc(torch.zeros(1, 3, 4, 64, 96, dtype=torch.float16, device=DEV), cache, stream=False)
+
+
+# ------------------------------------------------------------------------------------------------ sharded decode
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_row_sharded_decode_is_bit_identical(world):
+    """rtv_vae_decode_rows: every rank's stripe (stage 0 replicated, stages 1-3 on row windows with conv halos) must
+    equal the same rows of the unsharded decode bit for bit, across the first (9-frame) and later (12-frame) blocks."""
+    from oracle import vae_oracle as vo
+    from oracle.make_golden import vae_inputs
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    w = vo.make_vae_weights(seed=0)
+    full = VAEDecoderWrapper(DEV)
+    full.load_state_dict(w)
+    shards = [VAEDecoderWrapper(DEV, row_shard=(r, world)) for r in range(world)]
+    for s in shards:
+        s.load_state_dict(w)
+    cache = [None] * 55
+    caches = [[None] * 55 for _ in range(world)]
+    for z in vae_inputs(h=16, w=12)[:2]:
+        zz = z.half().to(DEV)
+        ref, cache = full(zz, *cache)
+        parts = []
+        for r, s in enumerate(shards):
+            px, caches[r] = s(zz, *caches[r])
+            r0, r1 = s.row_range(16)
+            assert px.shape == (1, ref.shape[1], 3, r1 - r0, 96)
+            parts.append(px)
+        assert torch.equal(torch.cat(parts, dim=3), ref)
+
+
+def test_gather_row_stripes_single_process():
+    from realtime_video_amd.parallel import SimulatedContextParallel, gather_row_stripes
+    cp = SimulatedContextParallel(1)
+    x = torch.randn(2, 3, 16, 8, device=DEV)
+    assert torch.equal(gather_row_stripes(cp, x, 16), x)
