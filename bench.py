@@ -114,11 +114,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # RTV_BENCH_SHARED_GPU=1 (test rigs with fewer GPUs than ranks): all ranks share cuda:0 and the collectives run over
+    # gloo staged through the host -- exercises the multi-rank code path, the numbers mean nothing
+    shared_gpu = os.environ.get("RTV_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
