@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--denoising-steps", type=int, default=4)
     ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-classes", default="gemm",
+                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm' (the roofline kernel, "
+                         "default), 'all' (diagnostic: every launch, costs a few %% of throughput) or 'none'")
     ap.add_argument("--keep-first-frame", action="store_true",
                     help="GenerateParams.keep_first_frame=True: skip the per-block first-frame VAE re-encode (A/B runs)")
     ap.add_argument("--gemm-tile-cfg", type=int, default=0)
@@ -177,7 +180,8 @@ def main():
         sess.generate_block()
     barrier()
     ops.prof_reset()
-    ops.prof_enable(True)
+    ops.prof_enable(args.profile_classes != "none",
+                    None if args.profile_classes == "all" else [c for c in args.profile_classes.split(",") if c != "none"])
     t0 = time.perf_counter()
     frames = 0
     for _ in range(args.steps):
@@ -226,10 +230,11 @@ def main():
                 f"cp{world}: one stream, token axis sharded {world}-way, K/V all-gather per layer over RCCL; VAE decode "
                 f"sharded by output rows ({world} stripes + conv halos, one pixel all-gather per block), first-frame "
                 f"re-encode replicated" if use_cp else f"{world} independent replicas"),
-            "dit_ms_per_forward": (prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
-                                   + prof["misc"]["ms"]) / (args.steps * fwd_per_block),
-            "vae_ms_per_block": prof["conv"]["ms"] / args.steps,
-            "kernel_ms_per_block": {k: v["ms"] / args.steps for k, v in prof.items()},
+            # kernel-class times exist only for the classes bracketed with events (--profile-classes; 'all' = diagnostic)
+            "dit_ms_per_forward": ((prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
+                                    + prof["misc"]["ms"]) / (args.steps * fwd_per_block)
+                                   if args.profile_classes == "all" else None),
+            "kernel_ms_per_block": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"] > 0},
         },
         "roofline": {
             "kernel": "gemm8_kernel / gemm_kernel (bf16 MFMA projection GEMMs with fused epilogues: all DiT linears)",

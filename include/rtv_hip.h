@@ -35,8 +35,10 @@ int rtv_version(void);
 const char* rtv_last_error(void);
 
 /* Per-kernel-class hipEvent timing (used by bench.py's roofline block).
- * class ids: 0 gemm, 1 attention, 2 layernorm/modulate, 3 rmsnorm+rope+cache, 4 conv, 5 misc */
-int rtv_prof_enable(int on);
+ * class ids: 0 gemm, 1 attention, 2 layernorm/modulate, 3 rmsnorm+rope+cache, 4 conv, 5 misc.
+ * rtv_prof_enable(mask): bit c set = bracket every launch of class c with two events (0 = off, 0x3f = all).  The event
+ * pairs serialise neighbouring launches, so a timed run enables only the class it reports. */
+int rtv_prof_enable(int class_mask);
 int rtv_prof_read(int cls, double* total_ms, int64_t* launches, double* total_work);
 int rtv_prof_reset(void);
 

@@ -31,7 +31,7 @@ struct ProfRec {
   hipEvent_t start, stop;
   double work;
 };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;  // bit c = time launches of class c
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_event_pool;
@@ -48,7 +48,7 @@ static hipEvent_t get_event() {
 }
 
 ProfScope::ProfScope(int cls, hipStream_t s, double work) : slot(-1), stream(s) {
-  if (!g_prof_on) return;
+  if (!((g_prof_mask >> cls) & 1u)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   ProfRec r;
   r.cls = cls;
@@ -75,8 +75,8 @@ int rtv_version(void) { return 100; }
 
 const char* rtv_last_error(void) { return g_err.c_str(); }
 
-int rtv_prof_enable(int on) {
-  g_prof_on = on != 0;
+int rtv_prof_enable(int class_mask) {
+  g_prof_mask = (unsigned)class_mask;
   return 0;
 }
 
