@@ -22,6 +22,7 @@ struct ProfScope {
 struct GemmParams;
 int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream);
 int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream);  // 256x256 ping-pong variant (gemm8.hip)
-int launch_gemm9(const GemmParams& p, bool f16, bool split, int dist, hipStream_t stream);  // 256x256 software-pipelined variant (gemm9.hip)
+int launch_gemm9(const GemmParams& p, bool f16, bool split, int dist, hipStream_t stream);
+int launch_gemm10(const GemmParams& p, bool f16, int abl, hipStream_t stream);  // 256x256, 4 waves of 128x128 (gemm10.hip)  // 256x256 software-pipelined variant (gemm9.hip)
 
 }  // namespace rtv

@@ -1,0 +1,76 @@
+// How much MFMA issue time does one LDS read / one LDS-DMA displace?  Each wave loops over 16 independent
+// v_mfma_f32_32x32x16_bf16 with R ds_read_b128 and D global_load_lds (16 B/lane, L2-resident source) issued behind
+// them (one per MFMA slot).  Reports SIMD cycles per 16-MFMA group vs the MFMA-only loop.
+// build: hipcc --offload-arch=gfx950 -O3 mfma_mix.hip -o mfma_mix ; run: mfma_mix <waves/SIMD 1|2>
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int R, int D>
+__global__ __launch_bounds__(512) void k(const char* src, int iters, float* out, long long* clk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  bf16x8 a[2], b[2];
+  for (int s = 0; s < 2; ++s)
+    for (int i = 0; i < 8; ++i) { a[s][i] = (__bf16)(0.01f * (lane + i + s)); b[s][i] = (__bf16)(0.02f * (lane - i) + s); }
+  f32x16 acc[8];
+  for (int n = 0; n < 8; ++n) for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  u32x4 frag[16];
+  for (int i = 0; i < 16; ++i) frag[i] = u32x4{0, 0, 0, 0};
+  const char* s = src + (size_t)(blockIdx.x & 7) * 65536 + lane * 16;
+  char* dst = smem + wave * 8192;
+  const unsigned rp = 65536 + wave * 4096 + lane * 16;
+  __syncthreads();
+  long long c0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      acc[n & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[n & 1], b[(n >> 1) & 1], acc[n & 7], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (n < R) asm volatile("ds_read_b128 %0, %1" : "=v"(frag[n]) : "v"(rp + (unsigned)((n & 3) * 1024)));
+      else if (n < R + D)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + ((it * 4 + n) & 63) * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + (n & 7) * 1024), 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (D) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  long long c1 = clock64();
+  float t = 0.f;
+  for (int n = 0; n < 8; ++n) for (int r = 0; r < 16; ++r) t += acc[n][r];
+  for (int i = 0; i < 16; ++i) t += (float)(frag[i][0] & 1);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = t;
+  if (blockIdx.x == 0 && lane == 0 && wave == 0) clk[0] = c1 - c0;
+}
+
+template <int R, int D>
+static void run(const char* src, float* out, long long* clk, int wps, int iters) {
+  hipFuncSetAttribute((const void*)k<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  k<R, D><<<256, 256 * wps, 131072>>>(src, iters, out, clk);
+  hipDeviceSynchronize();
+  long long h; hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
+  printf("waves/SIMD %d  reads %2d  dma %d : %7.1f cycles per 16 MFMA per wave (MFMA-only = %d)\n", wps, R, D,
+         (double)h / iters, 512 * wps);
+}
+
+int main(int argc, char** argv) {
+  int wps = argc > 1 ? atoi(argv[1]) : 2, iters = 20000;
+  char* src; float* out; long long* clk;
+  hipMalloc(&src, 9 * 65536); hipMemset(src, 1, 9 * 65536);
+  hipMalloc(&out, 256 * 512 * 4); hipMalloc(&clk, 8);
+  run<0, 0>(src, out, clk, wps, iters);
+  run<4, 0>(src, out, clk, wps, iters);
+  run<8, 0>(src, out, clk, wps, iters);
+  run<12, 0>(src, out, clk, wps, iters);
+  run<16, 0>(src, out, clk, wps, iters);
+  run<0, 2>(src, out, clk, wps, iters);
+  run<0, 4>(src, out, clk, wps, iters);
+  run<0, 8>(src, out, clk, wps, iters);
+  run<12, 4>(src, out, clk, wps, iters);
+  return 0;
+}
