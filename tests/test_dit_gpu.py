@@ -269,3 +269,36 @@ def test_session_first_frame_reencode_path():
     for b in range(3):
         ref = ora.generate_block()
         assert rel_l2(sess.all_latents[:, 3 * b:3 * b + 3].cpu(), ref) <= 5e-2, b
+
+
+def test_session_long_context_kv_cache_num_frames_9():
+    """BASELINE config 5's context length: kv_cache_num_frames = 9 (Lkv = 18720, recompute over up to 9 context frames
+    = 14040 tokens with the block-causal mask over three 3-frame blocks).  Four blocks on the tiny model with
+    keep_first_frame=True vs the CPU session oracle: block 3 recomputes over all nine earlier frames."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    cfg, text_dim, _ = _tiny()
+    cfg["num_layers"] = 1
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    g = torch.Generator().manual_seed(15)
+    ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
+    noise = torch.randn(1, 12, 16, 60, 104, generator=g).to(torch.bfloat16)
+    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=9, num_steps=2, shift=5.0, seed=4)
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 500]), DEV, generator=wr,
+                                   text_encoder=None, vae=None)
+    padded = torch.zeros(1, 512, text_dim, dtype=torch.bfloat16)
+    padded[0, :64] = ctx
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(padded.to(DEV)))
+    sess = GenerationSession(GenerateParams(seed=4, num_blocks=4, num_denoising_steps=2, kv_cache_num_frames=9,
+                                            keep_first_frame=True), models, device=DEV)
+    sess.noise = noise.to(DEV)
+    cpu_rnd = torch.Generator().manual_seed(4)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    for b in range(4):
+        out = sess.generate_block()
+        ref = ora.generate_block()
+        assert rel_l2(out.cpu(), ref) <= 5e-2, b
+    kv = pipe.kv_cache1[0]
+    assert kv["k"].shape[1] == 12 * 1560 and kv["local_end_index"] == 12 * 1560 and kv["global_end_index"] == 12 * 1560
