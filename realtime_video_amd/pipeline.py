@@ -48,7 +48,11 @@ class CausalInferencePipeline:
         cfg = self.generator.model.config
         shape = [batch_size, kv_cache_size, cfg.num_heads, cfg.dim // cfg.num_heads]
         if self.kv_cache1 and list(self.kv_cache1[0]["k"].shape) == shape and self.kv_cache1[0]["k"].dtype == dtype:
-            self._kv_arena.zero_()
+            # Reset.  The reference zero_()s all L x 2 tensors (causal_inference.py:296-303; 7.7 GB of HBM writes per block
+            # at 14B).  The forward only ever reads rows [.., local_end_index) and writes every row of that
+            # window first, so with `zero_on_reset = False` (set by GenerationSession) only the indices are reset.
+            if getattr(self, "zero_on_reset", True):
+                self._kv_arena.zero_()
             for c in self.kv_cache1:
                 c["global_end_index"] = 0
                 c["local_end_index"] = 0

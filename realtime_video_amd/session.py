@@ -86,6 +86,7 @@ class GenerationSession:
         for block in pipe.generator.model.blocks:
             block.self_attn.local_attn_size = -1
         pipe.local_attn_size = attn_size
+        pipe.zero_on_reset = False   # per-block cache reset = index reset only (output-identical, see pipeline.py)
         pipe._initialize_kv_cache(batch_size=1, dtype=torch.bfloat16, device=self.gpu)
         pipe._initialize_crossattn_cache(batch_size=1, dtype=torch.bfloat16, device=self.gpu)
         pipe.generator.model.block_mask = None
