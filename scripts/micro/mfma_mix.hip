@@ -9,8 +9,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <int R, int D>
-__global__ __launch_bounds__(512) void k(const char* src, int iters, float* out, long long* clk) {
+template <int R, int D, int G>
+__global__ __launch_bounds__(512) void k(const char* src, size_t span, int iters, float* out, long long* clk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   bf16x8 a[2], b[2];
@@ -20,7 +20,10 @@ __global__ __launch_bounds__(512) void k(const char* src, int iters, float* out,
   for (int n = 0; n < 8; ++n) for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
   u32x4 frag[16];
   for (int i = 0; i < 16; ++i) frag[i] = u32x4{0, 0, 0, 0};
-  const char* s = src + (size_t)(blockIdx.x & 7) * 65536 + lane * 16;
+  const char* s = src + lane * 16;
+  const size_t blk_off = (size_t)blockIdx.x * 262144;  // every block walks its own region of the source span
+  u32x4 stg[8];
+  for (int i = 0; i < 8; ++i) stg[i] = u32x4{0, 0, 0, 0};
   char* dst = smem + wave * 8192;
   const unsigned rp = 65536 + wave * 4096 + lane * 16;
   __syncthreads();
@@ -32,45 +35,54 @@ __global__ __launch_bounds__(512) void k(const char* src, int iters, float* out,
       __builtin_amdgcn_sched_barrier(0);
       if (n < R) asm volatile("ds_read_b128 %0, %1" : "=v"(frag[n]) : "v"(rp + (unsigned)((n & 3) * 1024)));
       else if (n < R + D)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + ((it * 4 + n) & 63) * 1024),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + ((blk_off + (size_t)(it * 16 + n) * 1024) & (span - 1))),
                                          (__attribute__((address_space(3))) void*)(dst + (n & 7) * 1024), 16, 0, 0);
+      else if (n < R + D + G) {   // write last iteration's piece to LDS, then reload the staging registers
+        const int q = n - R - D;
+        asm volatile("ds_write_b128 %0, %1" ::"v"((unsigned)(size_t)(dst - smem) + (unsigned)(q * 1024 + lane * 16)), "v"(stg[q]));
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg[q]) : "v"(s + ((blk_off + (size_t)(it * 16 + n) * 1024) & (span - 1))));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (D) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   long long c1 = clock64();
   float t = 0.f;
   for (int n = 0; n < 8; ++n) for (int r = 0; r < 16; ++r) t += acc[n][r];
   for (int i = 0; i < 16; ++i) t += (float)(frag[i][0] & 1);
+  for (int i = 0; i < 8; ++i) t += (float)(stg[i][1] & 1);
   out[blockIdx.x * blockDim.x + threadIdx.x] = t;
   if (blockIdx.x == 0 && lane == 0 && wave == 0) clk[0] = c1 - c0;
 }
 
-template <int R, int D>
-static void run(const char* src, float* out, long long* clk, int wps, int iters) {
-  hipFuncSetAttribute((const void*)k<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  k<R, D><<<256, 256 * wps, 131072>>>(src, iters, out, clk);
+template <int R, int D, int G>
+static void run(const char* src, size_t span, float* out, long long* clk, int wps, int iters) {
+  hipFuncSetAttribute((const void*)k<R, D, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  k<R, D, G><<<256, 256 * wps, 131072>>>(src, span, iters, out, clk);
   hipDeviceSynchronize();
   long long h; hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
-  printf("waves/SIMD %d  reads %2d  dma %d : %7.1f cycles per 16 MFMA per wave (MFMA-only = %d)\n", wps, R, D,
+  printf("span %5zu MiB waves/SIMD %d  reads %2d  dma %d  reg-staged %d : %7.1f cycles per 16 MFMA per wave (MFMA-only = %d)\n", span >> 20, wps, R, D, G,
          (double)h / iters, 512 * wps);
 }
 
 int main(int argc, char** argv) {
-  int wps = argc > 1 ? atoi(argv[1]) : 2, iters = 20000;
+  int wps = 1, iters = 4000;
+  size_t total = (size_t)1 << 30;
   char* src; float* out; long long* clk;
-  hipMalloc(&src, 9 * 65536); hipMemset(src, 1, 9 * 65536);
+  hipMalloc(&src, total + 65536); hipMemset(src, 1, total + 65536);
   hipMalloc(&out, 256 * 512 * 4); hipMalloc(&clk, 8);
-  run<0, 0>(src, out, clk, wps, iters);
-  run<4, 0>(src, out, clk, wps, iters);
-  run<8, 0>(src, out, clk, wps, iters);
-  run<12, 0>(src, out, clk, wps, iters);
-  run<16, 0>(src, out, clk, wps, iters);
-  run<0, 2>(src, out, clk, wps, iters);
-  run<0, 4>(src, out, clk, wps, iters);
-  run<0, 8>(src, out, clk, wps, iters);
-  run<12, 4>(src, out, clk, wps, iters);
+  for (size_t span : {(size_t)1 << 16, (size_t)1 << 30}) {   // L1/L2-resident source vs a 1 GiB walk (misses)
+    run<0, 0, 0>(src, span, out, clk, wps, iters);
+    run<12, 0, 0>(src, span, out, clk, wps, iters);
+    run<0, 4, 0>(src, span, out, clk, wps, iters);
+    run<0, 0, 4>(src, span, out, clk, wps, iters);
+    run<12, 4, 0>(src, span, out, clk, wps, iters);
+    run<12, 0, 4>(src, span, out, clk, wps, iters);
+    run<8, 8, 0>(src, span, out, clk, wps, iters);
+    run<8, 0, 8>(src, span, out, clk, wps, iters);
+  }
   return 0;
 }
