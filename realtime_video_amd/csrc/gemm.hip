@@ -147,8 +147,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
       return launch_gemm9(p, f16, true, 1, stream);   // A/B: prefetch distance 1 slab
     case 62:
       return launch_gemm9(p, f16, true, 2, stream);   //                       2 slabs
+    case 52:
+      return launch_gemm8(p, f16, 9, stream);      // A/B: as 50 with the phase barrier BEFORE the lgkmcnt(0) (no difference)
     case 50:
-      return launch_gemm8(p, f16, 1, stream);      // A/B variants: DMA pieces per LDS segment = 0
+      return launch_gemm8(p, f16, 1, stream);      // = the default for large problems: DMA between MFMAs + split-K
     case 51:
       return launch_gemm8(p, f16, 3, stream);      //                                            = 1
     default:

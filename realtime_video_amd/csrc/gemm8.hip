@@ -42,7 +42,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 
 }  // namespace g8
 
-template <bool F16, int NL>
+template <bool F16, int NL, bool SYNC_FIRST = false>
 __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
   typedef TileCfg<256, 256, 64, 2, 4> Cfg;  // epilogue geometry: 4 x 2 blocks of 32x32 per wave
@@ -141,14 +141,26 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
     G8_FENCE();                                         \
   } while (0)
-  // Phase = LDS segment [fragment reads, NL DMA pieces, counted vmcnt, lgkmcnt(0)] | barrier |
+  // Phase = LDS segment [fragment reads, NL DMA pieces, counted vmcnt] | barrier | lgkmcnt(0) |
   //         MFMA segment [8 MFMA + (2 - NL) DMA pieces between them] | barrier.
-  // The DMA pieces issued after the reads cover the reads' LDS latency, so retiring the reads before the barrier
-  // is free and makes re-staging a slot one phase after its last read strictly WAR-safe.
-#define G8_PHASE_SYNC() \
-  do {                  \
-    G8_LDS_DONE();      \
-    G8_BARRIER();       \
+  // SYNC_FIRST (A/B config 52, NL = 0): the phase's first barrier comes BEFORE the lgkmcnt(0) that retires the
+  // fragment reads, so the LDS latency of the reads overlaps the barrier wait instead of preceding it; measured equal to
+  // the default order (scripts/cold_gemm.py).  It stays WAR-safe: a wave retires its reads before its MFMAs,
+  // i.e. before the phase's SECOND barrier; the earliest restage of a slot (W0 of the current buffer, staged in phase 3,
+  // last read in phase 2) is issued after the stager's first barrier of phase 3, which every wave of its own group
+  // passes after that second barrier and every wave of the other group (one barrier behind) passes as its own second
+  // barrier of phase 2.  RAW is unchanged: the counted vmcnt still precedes the first barrier of phases 2 / 4 and the data
+  // is read a phase later.  With SYNC_FIRST = false the reads are retired before the barrier (the NL >= 1 variants need
+  // that: their LDS-segment DMA restages a slot one phase after its last read).
+#define G8_PHASE_SYNC()   \
+  do {                    \
+    if (SYNC_FIRST) {     \
+      G8_BARRIER();       \
+      G8_LDS_DONE();      \
+    } else {              \
+      G8_LDS_DONE();      \
+      G8_BARRIER();       \
+    }                     \
   } while (0)
 
   // MFMA segment of one phase: 8 MFMA on one 64x32 quadrant (+ the DMA pieces not issued in the LDS segment)
@@ -304,11 +316,11 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
   return 0;
 }
 
-template <bool F16, int NL>
+template <bool F16, int NL, bool SYNC_FIRST = false>
 static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   p.tiles_m = (p.M + g8::BM - 1) / g8::BM;
   p.tiles_n = (p.N + g8::BN - 1) / g8::BN;
-  auto kern = gemm8_kernel<F16, NL>;
+  auto kern = gemm8_kernel<F16, NL, SYNC_FIRST>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES);
@@ -326,7 +338,8 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
 int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream) {
   // variant: bit 0 = split-K of the tail round; bits 1.. = DMA pieces issued in the LDS segment (0, 1, 2)
   const bool split = variant & 1;
-  const int nl = variant >> 1;
+  const int nl = (variant >> 1) & 3;
+  if (variant & 8) return launch_gemm8_t<false, 0, true>(p, split, stream);  // A/B: barrier before the lgkmcnt wait
   if (f16) return launch_gemm8_t<true, 2>(p, split, stream);
   if (nl == 0) return launch_gemm8_t<false, 0>(p, split, stream);
   if (nl == 1) return launch_gemm8_t<false, 1>(p, split, stream);
