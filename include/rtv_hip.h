@@ -77,7 +77,9 @@ int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
  * 4 = 256x256 ping-pong pipeline (gemm8.hip); 5 = 4 + split-K of the last partial round of tiles (needs the
  * workspace below); 6 / 7 = 256x256 software-pipelined variant (gemm9.hip) without / with that split-K.  The split-K partial sums live in a caller-owned fp32 workspace: */
 size_t rtv_gemm_workspace_bytes(void);
-int rtv_gemm_set_workspace(void* ptr, size_t bytes);   /* ptr == NULL detaches it */
+int rtv_gemm_set_workspace(void* ptr, size_t bytes);   /* ptr == NULL detaches it.  Zeroes the arrival counters with a
+                                                          synchronous hipMemset (call it at set-up time, not under graph
+                                                          capture); launches leave the counters at zero. */
 
 /* ---- K5: fused norm / modulation / RoPE / KV-cache write ----------------------------------
  * rtv_layernorm_modulate: out = LN(x; eps, no affine) * (1 + scale[f]) + shift[f], f = (row_offset + m) / rows_per_frame

@@ -282,6 +282,9 @@ extern "C" int rtv_gemm_set_workspace(void* ptr, size_t bytes) {
   g_slabs = (float*)ptr;
   g_counters = (int*)((char*)ptr + (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4);
   g_ws_units = SPLIT_MAX_UNITS;
+  // arrival counters start at zero and every launch leaves them at zero (the reducer of a tile resets its counter)
+  if (hipMemset(g_counters, 0, (size_t)SPLIT_MAX_UNITS * sizeof(int)) != hipSuccess)
+    return set_error(-1, "gemm_set_workspace: cannot zero the arrival counters");
   return 0;
 }
 
@@ -309,8 +312,6 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       sp->slabs = g_slabs;
       sp->counters = g_counters;
       *grid = (T - R) + R * S;
-      if (hipMemsetAsync(g_counters, 0, (size_t)R * sizeof(int), stream) != hipSuccess)
-        return set_error(-1, "gemm: split-K counter memset failed");
     }
   }
   return 0;
