@@ -1,12 +1,15 @@
 """Mirror of the reference's streaming block loop: `GenerationSession` (release_server.py:344-751)
-restricted to the text-to-video hot path — `init_models` (:542-560), `get_clean_context_frames`
-(:563-576), `recompute_kv_cache` (:588-633), `generate_block_internal` (:636-736).  Host
-orchestration stays Python on PyTorch-ROCm exactly as in the reference; every forward it issues is the
-native `rtv_dit_forward` / VAE kernel path.  The web layer, webcam / v2v input side and prompt
-interpolation are outside the hot-path scope.
+restricted to the generation hot path — `init_models` (:542-560), `get_clean_context_frames`
+(:563-576), `recompute_kv_cache` (:588-633), `generate_block_internal` (:636-736), the streaming
+video-to-video input side `process_webcam_frames` (:489-527, frames handed in with `push_frame` instead of
+the server's WebSocket queue) and `interpolate_prompt_embeds` (:459-468).  Host orchestration stays Python
+on PyTorch-ROCm exactly as in the reference; every forward it issues is the native `rtv_dit_forward` / VAE
+kernel path.  The web layer (FastAPI / WebSocket / JPEG encoding) is outside the hot-path scope.
 """
 import types
 from collections import deque
+
+import numpy as np
 from dataclasses import dataclass
 from typing import Callable, Optional
 
@@ -26,6 +29,8 @@ class GenerateParams:
     strength: float = 1.0
     context_noise: float = 0.0
     keep_first_frame: bool = False
+    webcam_mode: bool = False          # streaming video-to-video: incoming frames are VAE-encoded every block
+    interp_blocks: int = -1
     kv_cache_num_frames: int = 3
     num_blocks: int = 9
     num_denoising_steps: Optional[int] = 5  # "use 4 for performance"
@@ -48,6 +53,14 @@ class StaticTextEncoder:
         return dict(self.cond)
 
 
+def resample_array(array, target_length):
+    """release_server.py:59-64: resample a list to the target length by linear interpolation of indices."""
+    if len(array) == target_length:
+        return array
+    indices = np.round(np.linspace(0, len(array) - 1, target_length)).astype(int)
+    return [array[i] for i in indices]
+
+
 class GenerationSession:
     def __init__(self, params: GenerateParams, models, frame_callback: Optional[Callable] = None, device="cuda"):
         self.params, self.models = params, models
@@ -60,6 +73,9 @@ class GenerationSession:
         self.num_blocks = params.num_blocks
         self.frame_context_cache = deque(maxlen=1 + (params.kv_cache_num_frames - 1) * 4)
         self.decode_vae_cache = [None] * 55
+        self.encode_vae_cache = [None] * 55
+        self.frame_queue = deque()                    # webcam / v2v input frames, [3, H, W] in [-1, 1] (release_server.py:470-487)
+        self.interpolated_prompt_embeds = []
         self.num_frame_per_block = 3
         self.rnd = torch.Generator(self.gpu).manual_seed(params.seed if params.seed is not None else 0)
         shape = [1, self.num_blocks * self.num_frame_per_block, 16, self.latent_height, self.latent_width]
@@ -95,6 +111,40 @@ class GenerationSession:
         st = pipe.scheduler.timesteps
         self.zero_padded_timesteps = torch.cat((st.cpu(), torch.tensor([0], dtype=torch.float32))).to(self.gpu)
         pipe.scheduler.to(self.gpu)
+
+    # release_server.py:459-468
+    def interpolate_prompt_embeds(self, models, new_prompt, interpolation_steps):
+        """Blend from the current prompt embedding to the new prompt's over the next `interpolation_steps` blocks."""
+        if self.current_prompt_embeds is None:
+            return
+        e1 = self.current_prompt_embeds
+        e2 = models.text_encoder(text_prompts=[new_prompt])["prompt_embeds"].to(dtype=torch.bfloat16)
+        x = torch.lerp(e1, e2, torch.linspace(0, 1, steps=interpolation_steps).unsqueeze(1).unsqueeze(2).to(e1))
+        self.interpolated_prompt_embeds = list(x.chunk(interpolation_steps, dim=0))
+
+    # release_server.py:470-487 (queue side) and :489-527
+    def push_frame(self, frame):
+        """Queue one input frame [3, H, W] in [-1, 1] (webcam / video-to-video mode)."""
+        self.frame_queue.append(frame)
+
+    def process_webcam_frames(self, models, idx):
+        """Encode the queued input frames of this block with the streaming VAE encoder: 9 frames for block 0 (fresh
+        caches: chunks 1 + 4 + 4), 12 afterwards (stream=True: 4 + 4 + 4) -> 3 latent frames.  Returns None when not
+        enough frames are queued (the reference's server thread polls here)."""
+        n = 9 if idx == 0 else 12
+        if len(self.frame_queue) < n:
+            return None
+        frame_list = list(self.frame_queue)
+        self.frame_queue.clear()
+        frames = torch.stack(resample_array(frame_list, n)).to(self.gpu)
+        latents, self.encode_vae_cache = encode_video_latent(models.vae_encoder, self.encode_vae_cache, frames=frames,
+                                                             height=self.params.height, width=self.params.width,
+                                                             stream=idx > 0)
+        return latents
+
+    def _randn_like(self, t):
+        """torch.randn_like of release_server.py:657 (global generator there); a hook for the tests."""
+        return torch.randn_like(t)
 
     # release_server.py:563-576
     def get_clean_context_frames(self, models):
@@ -154,8 +204,22 @@ class GenerationSession:
                 self.conditional_dict[k] = v.to(dtype=torch.bfloat16).contiguous()
             self.current_prompt_embeds = self.conditional_dict["prompt_embeds"]
         start = self.recompute_kv_cache(models)
-        noisy_input = self.noise[:, self.current_start_frame:self.current_start_frame + nfpb]
         steps = self.denoising_step_list
+        if self.params.webcam_mode:   # :651-657: start from the encoded input frames, noised to the first step's level
+            latents = self.process_webcam_frames(models, idx)
+            if latents is None:
+                return None
+            strength = steps[0] / 1000.0
+            latents = latents[None].to(self.gpu, dtype=self.noise.dtype).movedim(1, 2)
+            noisy_input = latents * (1.0 - strength) + self._randn_like(latents) * strength
+        else:
+            noisy_input = self.noise[:, self.current_start_frame:self.current_start_frame + nfpb]
+        if self.interpolated_prompt_embeds:   # :662-666: prompt transition -> new text K/V for the cross-attention
+            pipe._initialize_crossattn_cache(batch_size=1, dtype=torch.bfloat16, device=self.gpu)
+            nxt = self.interpolated_prompt_embeds.pop(0)
+            self.current_prompt_embeds = nxt.to(dtype=self.current_prompt_embeds.dtype,
+                                                device=self.current_prompt_embeds.device)
+        self.conditional_dict["prompt_embeds"] = self.current_prompt_embeds
         denoised_pred = None
         for index, current_timestep in enumerate(steps):
             timestep = torch.ones([1, nfpb], device=self.gpu, dtype=torch.int64) * current_timestep

@@ -302,3 +302,87 @@ def test_session_long_context_kv_cache_num_frames_9():
         assert rel_l2(out.cpu(), ref) <= 5e-2, b
     kv = pipe.kv_cache1[0]
     assert kv["k"].shape[1] == 12 * 1560 and kv["local_end_index"] == 12 * 1560 and kv["global_end_index"] == 12 * 1560
+
+
+def test_session_webcam_v2v_and_prompt_interpolation():
+    """Streaming video-to-video (release_server.py:489-527, :651-657): block 0 encodes 9 pushed frames on fresh encoder
+    caches (chunks 1+4+4), block 1 encodes 12 with stream=True; denoising starts from latents noised to the first step's
+    level.  Checked: the encoded latents vs the encoder oracle (eager fp16 on this GPU, same cache continuation), the DiT
+    blocks vs the CPU session oracle started from the same noisy latents, and a prompt interpolation that re-initialises
+    the cross-attention cache (:459-468, :662-666)."""
+    from oracle import vae_oracle as vo
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder, resample_array
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    assert resample_array(list(range(15)), 12) == [0, 1, 3, 4, 5, 6, 8, 9, 10, 11, 13, 14]
+    cfg, text_dim, _ = _tiny()
+    cfg["num_layers"] = 1
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    g = torch.Generator().manual_seed(7)
+    ctx = [torch.randn(64, text_dim, generator=g).to(torch.bfloat16) for _ in range(2)]
+    frames = torch.rand(21, 3, 480, 832, generator=g) * 2 - 1
+    eps = torch.randn(2, 1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
+
+    class TwoPrompts:   # text encoder stub: prompt "a" / "b" -> padded embeddings
+        def __call__(self, text_prompts=None):
+            e = torch.zeros(1, 512, text_dim, dtype=torch.bfloat16)
+            e[0, :64] = ctx[0 if text_prompts[0] == "a" else 1]
+            return {"prompt_embeds": e.to(DEV)}
+
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 500]), DEV, generator=wr)
+    enc_w = vo.make_vae_encoder_weights(seed=1)
+    enc = VAEEncoderWrapper(device=DEV)
+    enc.load_state_dict(enc_w)
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=TwoPrompts(), vae_encoder=enc)
+    sess = GenerationSession(GenerateParams(prompt="a", seed=1, num_blocks=2, num_denoising_steps=2, strength=0.7,
+                                            webcam_mode=True, keep_first_frame=True), models, device=DEV)
+    cpu_rnd = torch.Generator().manual_seed(1)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    seen = []
+
+    def fixed_randn_like(t):
+        seen.append(t.clone())
+        return eps[len(seen) - 1].to(DEV)
+    sess._randn_like = fixed_randn_like
+
+    assert sess.generate_block_internal(models) is None          # no frames queued yet
+    w16 = {k: v.half().to(DEV) for k, v in enc_w.items()}
+    cache16 = [None] * 55
+    noisy = []
+    strength = float(sess.denoising_step_list[0]) / 1000.0
+    assert abs(strength - float(wo.get_denoising_schedule(sess.zero_padded_timesteps.cpu(), 0.7, steps=2)[0]) / 1000.0) < 1e-6
+    for b, n in enumerate((9, 12)):
+        chunk = frames[:9] if b == 0 else frames[9:21]
+        for f in chunk:
+            sess.push_frame(f.half())
+        if b == 1:
+            sess.interpolate_prompt_embeds(models, "b", 2)        # lerp weights linspace(0, 1, 2) = [0, 1]: this block still
+            assert len(sess.interpolated_prompt_embeds) == 2      # sees prompt "a" (fresh cross-attn cache), the next one "b"
+        out = sess.generate_block()
+        assert out.shape == (1, 3, 16, 60, 104) and len(seen) == b + 1
+        mu16, cache16 = vo.encoder_wrapper_forward(w16, chunk.transpose(0, 1).unsqueeze(0).half().to(DEV), cache16, stream=b > 0)
+        lat_ref = mu16.movedim(1, 2).to(torch.bfloat16)
+        assert rel_l2(seen[b].float(), lat_ref.float()) <= 2e-2, b
+        noisy.append((seen[b] * (1.0 - strength) + eps[b].to(DEV) * strength).cpu())
+    assert torch.equal(sess.current_prompt_embeds[0, :64].cpu(), ctx[0])
+    assert len(sess.interpolated_prompt_embeds) == 1 and torch.equal(sess.interpolated_prompt_embeds[0][0, :64].cpu(), ctx[1])
+    assert all(c["is_init"] for c in pipe.crossattn_cache)
+
+    # DiT side vs the CPU oracle, started from the same noisy latents (the oracle reads them from its noise tensor)
+    ora = wo.SessionOracle(w, cfg, [ctx[0]], torch.cat(noisy, dim=1), kv_cache_num_frames=3, num_steps=2, shift=5.0, seed=1)
+    ora.denoising_step_list = sess.denoising_step_list.cpu()
+    for b in range(2):
+        if b == 1:   # prompt switch AFTER the KV recompute (which still sees the old prompt's cross-attention cache)
+            orig_recompute = ora.recompute_kv_cache
+
+            def recompute_then_switch():
+                start = orig_recompute()
+                ora.prompt_embeds = [ctx[0]]          # lerp weight 0: same prompt, but the cache is rebuilt
+                for c in ora.crossattn_cache:
+                    c["is_init"] = False
+                return start
+            ora.recompute_kv_cache = recompute_then_switch
+        ref = ora.generate_block()
+        assert rel_l2(sess.all_latents[:, 3 * b:3 * b + 3].cpu(), ref) <= 5e-2, b
