@@ -148,3 +148,11 @@ def test_rope_table_matches_reference_freqs(golden):
     t = rope_cos_sin_table(128)
     assert t.shape == (1024, 64, 2)
     assert torch.allclose(t[[0, 1, 5, 100, 1023]].double(), g["freqs_sample"], atol=1e-7)
+
+
+def test_resample_array_matches_reference_rule():
+    """release_server.py:59-64: np.round(np.linspace(0, len-1, target)) index pick."""
+    from realtime_video_amd.session import resample_array
+    assert resample_array([1, 2, 3], 3) == [1, 2, 3]
+    assert resample_array(list(range(24)), 12) == [0, 2, 4, 6, 8, 10, 13, 15, 17, 19, 21, 23]
+    assert resample_array(list(range(5)), 9) == [0, 0, 1, 2, 2, 2, 3, 4, 4]
