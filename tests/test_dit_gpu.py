@@ -386,3 +386,35 @@ def test_session_webcam_v2v_and_prompt_interpolation():
             ora.recompute_kv_cache = recompute_then_switch
         ref = ora.generate_block()
         assert rel_l2(sess.all_latents[:, 3 * b:3 * b + 3].cpu(), ref) <= 5e-2, b
+
+
+def test_config1_320x192_native_block_and_vae():
+    """BASELINE config 1's size on the native path: 320x192 (latents 24x40, 240 tokens per frame), 1.3B widths (one
+    layer), one block, one denoising step, VAE decode of the block (9 - 3 = 6 frames of 192x320).  Block 0 vs the
+    oracle (the reference's hard-coded frame_seqlen = 1560 only matters from block 1 on, SURVEY trap 3)."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.causal_model import CausalWanModel
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
+    cfg = dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=1, freq_dim=256, text_len=512, eps=1e-6)
+    w = wo.make_weights(cfg, seed=0, text_dim=64)
+    g = torch.Generator().manual_seed(2)
+    noise = torch.randn(1, 3, 16, 24, 40, generator=g).to(torch.bfloat16)
+    ctx = torch.randn(16, 64, generator=g).to(torch.bfloat16)
+    ref = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=1, shift=5.0, seed=0).generate_block()
+    m = CausalWanModel(dim=1536, ffn_dim=8960, num_heads=12, num_layers=1, text_dim=64, freq_dim=256, device=DEV)
+    m.load_state_dict(w)
+    wr = WanDiffusionWrapper(m, timestep_shift=5.0)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000]), DEV, generator=wr)
+    padded = torch.zeros(1, 512, 64, dtype=torch.bfloat16)
+    padded[0, :16] = ctx
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(padded.to(DEV)),
+                    vae_decoder=VAEDecoderWrapper(DEV).init_random_weights(seed=1))
+    sess = GenerationSession(GenerateParams(width=320, height=192, seed=0, num_blocks=1, num_denoising_steps=1,
+                                            keep_first_frame=True), models, device=DEV)
+    sess.noise = noise.to(DEV)
+    px = sess.generate_block()
+    assert px.shape == (1, 6, 3, 192, 320) and torch.isfinite(px).all() and float(px.abs().max()) <= 1.0
+    assert rel_l2(sess.all_latents.cpu(), ref) <= 5e-2

@@ -125,3 +125,20 @@ def test_gold_fp32_graph_bounds_bf16_error(golden):
                                  attn_fn=lambda q, k, v: wo.attention_sdpa(q, k, v, dtype=None))
     err = rel_l2(g["b0s0_flow"], flow)
     assert err <= 2e-2, err  # reference bf16 eager vs fp32 gold
+
+
+def test_config1_plumbing_320x192_one_block_one_step():
+    """BASELINE config 1 (plumbing, CPU eager): 1.3B widths, 320x192 -> latents [1,3,16,24,40] (240 tokens per frame),
+    one block, one denoising step through the oracle's block loop.  frame_seqlen is hard-coded to 1560 in the reference
+    (SURVEY trap 3), so only block 0 is meaningful at this size: shapes and finiteness are asserted, as the survey
+    prescribes; one layer keeps the CPU run short."""
+    from oracle import wan_oracle as wo
+    cfg = dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=1, freq_dim=256, text_len=512, eps=1e-6)
+    w = wo.make_weights(cfg, seed=0, text_dim=64)
+    g = torch.Generator().manual_seed(2)
+    noise = torch.randn(1, 3, 16, 24, 40, generator=g).to(torch.bfloat16)
+    ctx = torch.randn(16, 64, generator=g).to(torch.bfloat16)
+    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=1, shift=5.0, seed=0)
+    out = ora.generate_block()
+    assert out.shape == (1, 3, 16, 24, 40) and out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
+    assert ora.kv_cache[0]["global_end_index"] == 3 * 240 and ora.current_start_frame == 3
