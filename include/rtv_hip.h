@@ -200,6 +200,19 @@ int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_
                  void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 int rtv_dit_finish(const rtv_dit_config* cfg, const rtv_dit_step* step, const void* head_rows, rtv_stream_t stream);
 
+/* ---- optional fp8 weight path (BASELINE config 5; reference: release_server.py:179-182 = torchao
+ * Float8DynamicActivationFloat8WeightConfig(PerTensor) on every nn.Linear): OCP e4m3 operands, fp32 accumulation,
+ *   y = bf16( (q(x) . q(W)^T) * s_x * s_w + bias ), s = max|t| / 448 over the whole tensor, q(t) = e4m3(clamp(t / s, +-448)).
+ * rtv_quantize_fp8: x [M, d] bf16 (row stride ld) -> q [M, d] e4m3 (row stride ldq bytes) and *scale_out = s_x (device float);
+ *   amax_scratch = 4 device bytes.  d % 16 == 0.
+ * rtv_gemm_fp8: C[M,N] bf16 = epilogue((A . W^T) * a_scale[0] * w_scale): A [M,K], W [N,K] e4m3 (lda / ldw in bytes, K % 128 == 0);
+ *   the epilogue arguments are rtv_gemm's.  Uses the split-K workspace of rtv_gemm_set_workspace when attached. */
+int rtv_quantize_fp8(const void* x, int64_t ld, int M, int d, void* q, int64_t ldq, float* scale_out, void* amax_scratch,
+                     rtv_stream_t stream);
+int rtv_gemm_fp8(const void* A, int lda, const void* W, int ldw, const float* a_scale, float w_scale, void* C, int ldc,
+                 int M, int N, int K, const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame,
+                 int row_offset, const void* residual, int ldr, rtv_stream_t stream);
+
 /* ---- K6/K7: streaming VAE decoder / encoder -----------------------------------------------------
  * fp16, channels-last activations [T][H][W][C].
  * rtv_conv_cl: implicit-GEMM convolution replacing CausalConv3d / Conv2d / time_conv of the VAE

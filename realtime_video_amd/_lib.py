@@ -19,6 +19,9 @@ c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes
 # name -> argtypes (restype is always int except where noted); mirrors include/rtv_hip.h
 SIGNATURES = {
     "rtv_version": [],
+    "rtv_quantize_fp8": [c_vp, c_i64, c_int, c_int, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "rtv_gemm_fp8": [c_vp, c_int, c_vp, c_int, c_vp, c_f32, c_vp, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int,
+                     c_int, c_int, c_vp, c_int, c_vp],
     "rtv_prof_enable": [c_int],
     "rtv_prof_read": [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
                       ctypes.POINTER(ctypes.c_double)],

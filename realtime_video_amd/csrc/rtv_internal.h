@@ -23,6 +23,11 @@ struct GemmParams;
 int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream);
 int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream);  // 256x256 ping-pong variant (gemm8.hip)
 int launch_gemm9(const GemmParams& p, bool f16, bool split, int dist, hipStream_t stream);
+// fp8 (e4m3) path, gemm_fp8.hip: dynamic per-tensor activation quantisation + 256x256 fp8 GEMM with the bf16 epilogue
+int launch_quantize_fp8(const uint16_t* x, int64_t ld, int M, int d, uint8_t* q, int64_t ldq, float* scale_out,
+                        unsigned* amax_scratch, hipStream_t stream);
+int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* a_scale, float w_scale,
+                    hipStream_t stream);
 int launch_gemm10(const GemmParams& p, bool f16, int abl, hipStream_t stream);  // 256x256, 4 waves of 128x128 (gemm10.hip)  // 256x256 software-pipelined variant (gemm9.hip)
 
 }  // namespace rtv

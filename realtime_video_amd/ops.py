@@ -122,6 +122,42 @@ def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame
     return out
 
 
+# --------------------------------------------------------------------------------------- fp8 path
+def quantize_fp8(x, out=None):
+    """Dynamic per-tensor e4m3 quantisation of a bf16 matrix (torchao PerTensor semantics): returns (q, scale) with
+    q = e4m3(clamp(x / scale, +-448)) as a torch.float8_e4m3fn tensor and scale = max|x| / 448 as a 1-element fp32 tensor."""
+    _gpu(x)
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or x.stride(1) != 1:
+        raise TypeError("quantize_fp8 expects a K-contiguous bf16 matrix")
+    M, d = x.shape
+    if out is None:
+        out = torch.empty((M, d), dtype=torch.float8_e4m3fn, device=x.device)
+    scale = torch.empty(1, dtype=torch.float32, device=x.device)
+    scratch = torch.empty(1, dtype=torch.int32, device=x.device)
+    _lib.call("rtv_quantize_fp8", _ptr(x), ctypes.c_int64(x.stride(0)), M, d, _ptr(out), ctypes.c_int64(out.stride(0)),
+              _ptr(scale), _ptr(scratch), _stream())
+    return out, scale
+
+
+def gemm_fp8(a_q, a_scale, w_q, w_scale, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame=0,
+             residual=None, out=None, row_offset=0):
+    """out[M,N] bf16 = epi((a_q @ w_q^T) * a_scale * w_scale): e4m3 operands, fp32 accumulation, rtv_gemm's epilogue."""
+    _gpu(a_q, w_q, a_scale, bias, gate, residual, out)
+    if a_q.dtype != torch.float8_e4m3fn or w_q.dtype != torch.float8_e4m3fn:
+        raise TypeError("gemm_fp8 expects float8_e4m3fn operands")
+    M, K = a_q.shape
+    N = w_q.shape[0]
+    if w_q.shape[1] != K or a_q.stride(1) != 1 or w_q.stride(1) != 1:
+        raise ValueError("gemm_fp8 shape / stride mismatch")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a_q.device)
+    ensure_gemm_workspace(a_q.device)
+    _lib.call("rtv_gemm_fp8", _ptr(a_q), a_q.stride(0), _ptr(w_q), w_q.stride(0), _ptr(a_scale), ctypes.c_float(float(w_scale)),
+              _ptr(out), out.stride(0), M, N, K, _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame),
+              int(row_offset), _ptr(residual), residual.stride(0) if residual is not None else 0, _stream())
+    return out
+
+
 # --------------------------------------------------------------------------------------- norms
 def layernorm_modulate(x, eps=1e-6, shift=None, scale=None, frame_stride=0, rows_per_frame=0,
                        weight=None, bias=None, out=None, row_offset=0):

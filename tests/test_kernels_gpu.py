@@ -317,3 +317,54 @@ def test_attention_rows_independent_of_wave_grouping(ops):
     for off in (4, 37, 300):
         part = ops.attn_fwd(q[:, off:].contiguous(), k, v)
         assert torch.equal(part, full[:, off:]), off
+
+
+# ----------------------------------------------------------------------------------------- fp8 path
+def _fp8_linear_ref(x, w, bias):
+    """torchao Float8DynamicActivationFloat8WeightConfig(PerTensor) restated: per-tensor scales max|t|/448, e4m3 operands,
+    fp32 products/accumulation, bias added before the bf16 rounding."""
+    sx = x.float().abs().max().clamp(min=1e-12) / 448.0
+    sw = w.float().abs().max().clamp(min=1e-12) / 448.0
+    xq = (x.float() / sx).clamp(-448, 448).to(torch.float8_e4m3fn)
+    wq = (w.float() / sw).clamp(-448, 448).to(torch.float8_e4m3fn)
+    y = (xq.float() @ wq.float().t()) * (sx * sw)
+    if bias is not None:
+        y = y + bias.float()
+    return y, xq, wq, sx, sw
+
+
+def test_quantize_fp8_matches_torch_e4m3(ops):
+    x = (_randn(1000, 512, seed=5) * 3).contiguous()
+    q, s = ops.quantize_fp8(x)
+    _, xq, _, sx, _ = _fp8_linear_ref(x, x[:8], None)
+    assert abs(float(s) - float(sx)) <= 1e-7 * float(sx)
+    assert torch.equal(q.view(torch.uint8), xq.view(torch.uint8))          # same rounding (RNE), same saturation
+    z, sz = ops.quantize_fp8(torch.zeros(16, 128, dtype=torch.bfloat16, device=DEV))
+    assert float(z.float().abs().max()) == 0 and float(sz) > 0
+
+
+@pytest.mark.parametrize("M,N,K", [(4680, 5120, 1024), (300, 1536, 256), (2340, 13824, 512), (4680, 2560, 5120)])
+def test_gemm_fp8_matches_scaled_mm_restatement(ops, M, N, K):
+    a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+    ref, _, wq, _, sw = _fp8_linear_ref(a, w, b)
+    for _ in range(3):
+        aq, sa = ops.quantize_fp8(a)
+        out = ops.gemm_fp8(aq, sa, wq, float(sw), bias=b)
+        assert rel_l2(out, ref.to(torch.bfloat16)) <= 4e-3
+    # and the fp8 result is close to the bf16 GEMM (quantisation noise of two e4m3 operands)
+    assert rel_l2(out, (a.float() @ w.float().t() + b.float())) <= 6e-2
+
+
+def test_gemm_fp8_fused_epilogue(ops):
+    M, N, K, F = 4680, 1536, 1536, 3
+    a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+    gate, res = _randn(F, N, seed=4), _randn(M, N, seed=5)
+    y, _, wq, _, sw = _fp8_linear_ref(a, w, b)
+    yb = y.to(torch.bfloat16)
+    g = gate.repeat_interleave(M // F, dim=0)
+    ref = res + (yb * g)                                     # bf16(acc+bias) -> * gate -> + residual, as rtv_gemm
+    aq, sa = ops.quantize_fp8(a)
+    out = ops.gemm_fp8(aq, sa, wq, float(sw), bias=b, gate=gate, gate_stride=N, rows_per_frame=M // F, residual=res)
+    assert rel_l2(out, ref) <= 4e-3
+    out = ops.gemm_fp8(aq, sa, wq, float(sw), bias=b, act=1)
+    assert rel_l2(out, torch.nn.functional.gelu(yb, approximate="tanh")) <= 4e-3
