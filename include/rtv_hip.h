@@ -136,6 +136,7 @@ typedef struct rtv_dit_config {
   int freq_dim, text_dim, text_len;
   int in_dim, out_dim;          /* latent channels (16, 16); patch size is (1,2,2) */
   float eps;
+  int use_fp8;                  /* 1: every nn.Linear runs the e4m3 path (weights below are e4m3, fp8_scales set) */
 } rtv_dit_config;
 
 typedef struct rtv_dit_layer_weights { /* bf16 device pointers, reference state_dict names in comments */
@@ -158,6 +159,9 @@ typedef struct rtv_dit_weights {
   const void *head_modulation;        /* head.modulation [2][d] */
   const void *rope_cs;                /* float2 [1024][head_dim/2] */
   const rtv_dit_layer_weights* layers; /* host array [num_layers] */
+  const float* fp8_scales;            /* fp8 mode: host array of per-tensor weight scales: text0, text2, time0, time2, tproj,
+                                         head, then per layer qkv, o, cq, ck, cv, co, ffn0, ffn2 (6 + 8 L entries); the *_w
+                                         pointers of those linears then address e4m3 [N][K] data.  NULL otherwise */
 } rtv_dit_weights;
 
 typedef struct rtv_dit_step {

@@ -148,8 +148,51 @@ def initialize_crossattn_cache(num_layers, batch_size, num_heads, head_dim, dtyp
 # ------------------------------------------------------------------------------------------------
 # DiT block
 # ------------------------------------------------------------------------------------------------
+FP8_FLAG = "__fp8__"   # weights[FP8_FLAG] = True switches every nn.Linear to the fp8 restatement below
+_FP8_MAX = 448.0
+
+
+def _fp8_scale(t):
+    """Per-tensor scale max|t| / 448 as torchao's choose-scale evaluates it on the GPU (`amax / 448.0` with a Python scalar
+    = multiplication by the fp32 reciprocal), clamped away from zero."""
+    inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(_FP8_MAX, dtype=torch.float32)
+    return t.detach().float().abs().max().clamp(min=1e-12) * inv.to(t.device)
+
+
+def fp8_linear(x, weight, bias):
+    """nn.Linear under the reference's `enable_fp8` (release_server.py:179-182):
+    torchao.quantize_(transformer, Float8DynamicActivationFloat8WeightConfig(granularity=PerTensor())).  torchao is not
+    part of the reference tree (third-party, unpinned): this restates its published algorithm - dynamic per-tensor
+    activation scale, static per-tensor weight scale, e4m3 (OCP, saturating at 448, round-to-nearest-even) operands,
+    fp32 accumulation and bias inside torch._scaled_mm, output in the activation dtype.  PARITY UNPINNED for this mode:
+    no golden from the real torchao can be minted offline."""
+    sx, sw = _fp8_scale(x), _fp8_scale(weight)
+    xq = (x.float() / sx).clamp(-_FP8_MAX, _FP8_MAX).to(torch.float8_e4m3fn).float()
+    wq = (weight.float() / sw).clamp(-_FP8_MAX, _FP8_MAX).to(torch.float8_e4m3fn).float()
+    y = F.linear(xq, wq) * (sx * sw)
+    if bias is not None:
+        y = y + bias.float()
+    return y.to(x.dtype)
+
+
+def _linear(w, x, weight, bias):
+    if w.get(FP8_FLAG):
+        return fp8_linear(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 def _lin(x, w, prefix):
-    return F.linear(x, w[prefix + ".weight"], w[prefix + ".bias"])
+    return _linear(w, x, w[prefix + ".weight"], w[prefix + ".bias"])
+
+
+def _qkv(x, w, pre):
+    """self_attn q / k / v projections.  In fp8 mode the reference quantises the FUSED to_qkv Linear (fuse_projections runs
+    before quantize_, release_server.py:176-182): one weight scale over [3d, d], one activation quantisation."""
+    if not w.get(FP8_FLAG):
+        return _lin(x, w, pre + ".q"), _lin(x, w, pre + ".k"), _lin(x, w, pre + ".v")
+    wq = torch.cat([w[pre + ".q.weight"], w[pre + ".k.weight"], w[pre + ".v.weight"]])
+    bq = torch.cat([w[pre + ".q.bias"], w[pre + ".k.bias"], w[pre + ".v.bias"]])
+    return fp8_linear(x, wq, bq).chunk(3, dim=-1)
 
 
 def self_attention(w, pre, x, grid, freqs, num_heads, kv_cache, current_start, recompute,
@@ -160,9 +203,10 @@ def self_attention(w, pre, x, grid, freqs, num_heads, kv_cache, current_start, r
     b, s, n = x.shape[0], x.shape[1], num_heads
     d = x.shape[2] // n
     attn_fn = attn_fn or attention_sdpa
-    q = rms_norm(_lin(x, w, pre + ".q"), w[pre + ".norm_q.weight"], eps).view(b, s, n, d)
-    k = rms_norm(_lin(x, w, pre + ".k"), w[pre + ".norm_k.weight"], eps).view(b, s, n, d)
-    v = _lin(x, w, pre + ".v").view(b, s, n, d)
+    q_, k_, v_ = _qkv(x, w, pre)
+    q = rms_norm(q_, w[pre + ".norm_q.weight"], eps).view(b, s, n, d)
+    k = rms_norm(k_, w[pre + ".norm_k.weight"], eps).view(b, s, n, d)
+    v = v_.reshape(b, s, n, d)
 
     if recompute:
         rq = rope_apply(q, grid, freqs).type_as(v)
@@ -250,7 +294,7 @@ def head(w, x, e, eps=1e-6):
     num_frames, frame_seqlen = e.shape[1], x.shape[1] // e.shape[1]
     e = (w["head.modulation"].unsqueeze(1) + e).chunk(2, dim=2)
     h = layer_norm(x, eps).unflatten(dim=1, sizes=(num_frames, frame_seqlen)) * (1 + e[1]) + e[0]
-    return F.linear(h, w["head.head.weight"], w["head.head.bias"])
+    return _linear(w, h, w["head.head.weight"], w["head.head.bias"])
 
 
 def unpatchify(x, grid, out_dim=16, patch_size=(1, 2, 2)):
@@ -277,14 +321,14 @@ def model_forward(w, cfg, x, t, context, kv_cache, crossattn_cache, current_star
     grid = tuple(xs[0].shape[2:])
     xs = torch.cat([u.flatten(2).transpose(1, 2) for u in xs])
     e = sinusoidal_embedding_1d(cfg.get("freq_dim", 256), t.flatten()).type_as(xs)
-    e = F.linear(F.silu(F.linear(e, w["time_embedding.0.weight"], w["time_embedding.0.bias"])),
-                 w["time_embedding.2.weight"], w["time_embedding.2.bias"])
-    e0 = F.linear(F.silu(e), w["time_projection.1.weight"], w["time_projection.1.bias"]) \
+    e = _linear(w, F.silu(_linear(w, e, w["time_embedding.0.weight"], w["time_embedding.0.bias"])),
+                w["time_embedding.2.weight"], w["time_embedding.2.bias"])
+    e0 = _linear(w, F.silu(e), w["time_projection.1.weight"], w["time_projection.1.bias"]) \
         .unflatten(1, (6, dim)).unflatten(dim=0, sizes=t.shape)
     text_len = cfg.get("text_len", 512)
     ctx = torch.stack([torch.cat([u, u.new_zeros(text_len - u.size(0), u.size(1))]) for u in context])
-    ctx = F.linear(F.gelu(F.linear(ctx, w["text_embedding.0.weight"], w["text_embedding.0.bias"]),
-                          approximate="tanh"), w["text_embedding.2.weight"], w["text_embedding.2.bias"])
+    ctx = _linear(w, F.gelu(_linear(w, ctx, w["text_embedding.0.weight"], w["text_embedding.0.bias"]),
+                            approximate="tanh"), w["text_embedding.2.weight"], w["text_embedding.2.bias"])
     h = xs
     for i in range(cfg["num_layers"]):
         h = attention_block(w, f"blocks.{i}", h, e0, grid, freqs, ctx, n_heads, kv_cache[i],

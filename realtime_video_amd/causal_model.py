@@ -23,7 +23,8 @@ c_vp = ctypes.c_void_p
 
 class _Cfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("dim", "ffn_dim", "num_heads", "num_layers", "freq_dim", "text_dim",
-                                            "text_len", "in_dim", "out_dim")] + [("eps", ctypes.c_float)]
+                                            "text_len", "in_dim", "out_dim")] + [("eps", ctypes.c_float),
+                                                                                  ("use_fp8", ctypes.c_int)]
 
 
 _LAYER_FIELDS = ("qkv_w", "qkv_b", "norm_q_w", "norm_k_w", "o_w", "o_b", "norm3_w", "norm3_b",
@@ -41,7 +42,13 @@ _TOP_FIELDS = ("patch_w", "patch_b", "text0_w", "text0_b", "text2_w", "text2_b",
 
 
 class _Weights(ctypes.Structure):
-    _fields_ = [(n, c_vp) for n in _TOP_FIELDS] + [("layers", ctypes.POINTER(_LayerW))]
+    _fields_ = [(n, c_vp) for n in _TOP_FIELDS] + [("layers", ctypes.POINTER(_LayerW)),
+                                                   ("fp8_scales", ctypes.POINTER(ctypes.c_float))]
+
+
+# nn.Linear weights in the order of rtv_dit_weights.fp8_scales (include/rtv_hip.h)
+_FP8_TOP = ("text0_w", "text2_w", "time0_w", "time2_w", "tproj_w", "head_w")
+_FP8_LAYER = ("qkv_w", "o_w", "cq_w", "ck_w", "cv_w", "co_w", "ffn0_w", "ffn2_w")
 
 
 class _Step(ctypes.Structure):
@@ -125,7 +132,7 @@ class CausalWanModel:
         self._tensors = {}      # name -> device tensor (keeps the memory alive)
         self._w = None          # ctypes weight table
         self._ws = {}           # (F, gh, gw) -> workspace tensor
-        self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps)
+        self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps, 0)
 
     # ------------------------------------------------------------------ nn.Module-ish conveniences
     def eval(self):
@@ -189,6 +196,44 @@ class CausalWanModel:
         self._layers_arr = layers
         self._tensors, self._w = t, w
         return [], []
+
+    def enable_fp8(self):
+        """The reference's `enable_fp8` switch (release_server.py:179-182: torchao quantize_ with
+        Float8DynamicActivationFloat8WeightConfig(PerTensor) over every nn.Linear, after fuse_projections): weights become
+        e4m3 with one scale per tensor (max|W| / 448), activations are quantised per call inside the forward
+        (rtv_quantize_fp8), products accumulate in fp32 (rtv_gemm_fp8).  The Conv3d patch embedding is not an nn.Linear and
+        stays bf16.  Call after load_state_dict / init_random_weights; the bf16 copies of the quantised weights are freed."""
+        if self._w is None:
+            raise RuntimeError("load weights before enable_fp8()")
+        if self._cfg.use_fp8:
+            return self
+        for k in (self.dim, self.ffn_dim, self.text_dim, self.freq_dim):
+            if k % 128:
+                raise ValueError("enable_fp8: every Linear input width must be a multiple of 128")
+        if self.context_parallel is not None:
+            raise NotImplementedError("fp8 with context parallelism needs an all-reduce of the per-tensor activation scales")
+        scales = (ctypes.c_float * (len(_FP8_TOP) + len(_FP8_LAYER) * self.num_layers))()
+
+        def quant(key):
+            w = self._tensors[key]
+            s = w.float().abs().max().clamp(min=1e-12) / 448.0      # on the GPU, like torchao's choose-scale
+            q = (w.float() / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).contiguous()
+            self._tensors[key] = q
+            return q, float(s)
+
+        for i, name in enumerate(_FP8_TOP):
+            q, scales[i] = quant(name)
+            setattr(self._w, name, q.data_ptr())
+        for l in range(self.num_layers):
+            for j, name in enumerate(_FP8_LAYER):
+                q, scales[len(_FP8_TOP) + len(_FP8_LAYER) * l + j] = quant(f"L{l}.{name}")
+                setattr(self._layers_arr[l], name, q.data_ptr())
+        self._fp8_scales = scales
+        self._w.fp8_scales = ctypes.cast(scales, ctypes.POINTER(ctypes.c_float))
+        self._cfg.use_fp8 = 1
+        self._ws.clear()                  # the workspace grows by the fp8 activation buffer
+        ops.ensure_gemm_workspace(self.device)
+        return self
 
     def init_random_weights(self, seed=0, std=0.02):
         """Synthetic weights of the right architecture generated directly on the GPU (bench.py: there is no

@@ -32,6 +32,8 @@ struct Workspace {
 struct DitBuffers {
   uint16_t *x, *xn, *qkv, *q, *ao, *h, *prow, *hrow;
   uint16_t *sinus, *te1, *e, *se, *e0, *emod, *ehead, *ctx1, *ctx, *ktmp;
+  uint8_t* q8;      // fp8 path: the quantised activation of the linear being computed
+  float* fscale;    // fp8 path: its per-tensor scale (device), followed by the 4-byte absmax scratch
 };
 
 // Buffers are sized for the full token count so that one workspace serves sharded and unsharded calls.
@@ -58,6 +60,14 @@ static size_t carve(const rtv_dit_config* c, int F, int gh, int gw, char* base, 
   t.ctx1 = (uint16_t*)ws.take((size_t)c->text_len * d * e);
   t.ctx = (uint16_t*)ws.take((size_t)c->text_len * d * e);
   t.ktmp = (uint16_t*)ws.take((size_t)c->text_len * d * e);
+  {
+    size_t rows = M > (size_t)c->text_len ? M : (size_t)c->text_len, k = d;
+    if ((size_t)c->ffn_dim > k) k = c->ffn_dim;
+    if ((size_t)c->text_dim > k) k = c->text_dim;
+    if ((size_t)c->freq_dim > k) k = c->freq_dim;
+    t.q8 = (uint8_t*)ws.take(c->use_fp8 ? rows * k : 0);
+    t.fscale = (float*)ws.take(256);
+  }
   if (b) *b = t;
   if (ok) *ok = ws.ok;
   return ws.off;
@@ -130,9 +140,20 @@ extern "C" size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int 
 }
 
 // nn.Linear on `M` rows with optional fused epilogue; `row_off` = global index of row 0 for the per-frame gate.
-static int linear(const void* a, int K, const void* w, const void* bias, void* out, int M, int N, int act,
+// fp8 mode (cfg->use_fp8, release_server.py:179-182): every nn.Linear quantises its input per tensor (dynamic) and
+// multiplies e4m3 operands; `sidx` indexes the weight's per-tensor scale in rtv_dit_weights.fp8_scales (< 0: the op is
+// not an nn.Linear - the Conv3d patch embedding - and stays bf16).
+enum { S_TEXT0 = 0, S_TEXT2, S_TIME0, S_TIME2, S_TPROJ, S_HEAD, S_LAYER0 };
+enum { S_QKV = 0, S_O, S_CQ, S_CK, S_CV, S_CO, S_FFN0, S_FFN2, S_PER_LAYER };
+static int linear(Ctx& c, int sidx, const void* a, int K, const void* w, const void* bias, void* out, int M, int N, int act,
                   const void* gate, int gate_stride, int rpf, int row_off, const void* res, int cfg, rtv_stream_t s) {
-  return rtv_gemm(a, K, w, K, out, N, M, N, K, bias, act, gate, gate_stride, rpf, row_off, res, N, RTV_DTYPE_BF16, cfg, s);
+  if (!c.cfg->use_fp8 || sidx < 0)
+    return rtv_gemm(a, K, w, K, out, N, M, N, K, bias, act, gate, gate_stride, rpf, row_off, res, N, RTV_DTYPE_BF16, cfg, s);
+  if (!c.w->fp8_scales) return set_error(-1, "dit: use_fp8 needs rtv_dit_weights.fp8_scales");
+  if (c.rc != c.M) return set_error(-1, "dit: the fp8 path is not token-sharded yet (per-tensor activation scales need an all-reduce)");
+  if (rtv_quantize_fp8(a, K, M, K, c.b.q8, K, c.b.fscale, c.b.fscale + 1, s)) return -1;
+  return rtv_gemm_fp8(c.b.q8, K, w, K, c.b.fscale, c.w->fp8_scales[sidx], out, N, M, N, K, bias, act, gate, gate_stride, rpf,
+                      row_off, res, N, s);
 }
 
 // ---- embeddings, modulation tables, cross-attention K/V (causal_model.py:874-902)
@@ -145,12 +166,12 @@ static int dit_begin(Ctx& c) {
   rtv_stream_t stream = c.stream;
   const int pk = cfg->in_dim * 4;
   RTV_TRY(rtv_patchify(st->x, b.prow, cfg->in_dim, F, c.gh, c.gw, stream));
-  RTV_TRY(linear(b.prow + (size_t)c.r0 * pk, pk, w->patch_w, w->patch_b, b.x, c.rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(c, -1, b.prow + (size_t)c.r0 * pk, pk, w->patch_w, w->patch_b, b.x, c.rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
   RTV_TRY(rtv_sinusoidal_embedding(st->t, b.sinus, F, cfg->freq_dim, stream));
-  RTV_TRY(linear(b.sinus, cfg->freq_dim, w->time0_w, w->time0_b, b.te1, F, d, RTV_ACT_SILU, nullptr, 0, 0, 0, nullptr, tc, stream));
-  RTV_TRY(linear(b.te1, d, w->time2_w, w->time2_b, b.e, F, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(c, S_TIME0, b.sinus, cfg->freq_dim, w->time0_w, w->time0_b, b.te1, F, d, RTV_ACT_SILU, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(c, S_TIME2, b.te1, d, w->time2_w, w->time2_b, b.e, F, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
   RTV_TRY(rtv_silu(b.e, b.se, (int64_t)F * d, stream));
-  RTV_TRY(linear(b.se, d, w->tproj_w, w->tproj_b, b.e0, F, 6 * d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(c, S_TPROJ, b.se, d, w->tproj_w, w->tproj_b, b.e0, F, 6 * d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
   RTV_TRY(rtv_modulation_table(w->modulation, b.e0, b.emod, L, F, 6, 6, d, stream));
   RTV_TRY(rtv_modulation_table(w->head_modulation, b.e, b.ehead, 1, F, 2, 1, d, stream));
   // text context -> cross-attention K/V caches, only while they are not initialised (model.py:186-192;
@@ -158,13 +179,13 @@ static int dit_begin(Ctx& c) {
   if (st->compute_cross_kv) {
     if (!st->context) return set_error(-1, "dit: context required to initialise the cross-attention cache");
     const int T = cfg->text_len;
-    RTV_TRY(linear(st->context, cfg->text_dim, w->text0_w, w->text0_b, b.ctx1, T, d, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
-    RTV_TRY(linear(b.ctx1, d, w->text2_w, w->text2_b, b.ctx, T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+    RTV_TRY(linear(c, S_TEXT0, st->context, cfg->text_dim, w->text0_w, w->text0_b, b.ctx1, T, d, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
+    RTV_TRY(linear(c, S_TEXT2, b.ctx1, d, w->text2_w, w->text2_b, b.ctx, T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
     for (int l = 0; l < L; ++l) {
       const rtv_dit_layer_weights& lw = w->layers[l];
-      RTV_TRY(linear(b.ctx, d, lw.ck_w, lw.ck_b, b.ktmp, T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+      RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_CK, b.ctx, d, lw.ck_w, lw.ck_b, b.ktmp, T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
       RTV_TRY(rtv_rmsnorm(b.ktmp, d, st->ca_k[l], d, T, d, cfg->eps, lw.cnorm_k_w, stream));
-      RTV_TRY(linear(b.ctx, d, lw.cv_w, lw.cv_b, st->ca_v[l], T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+      RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_CV, b.ctx, d, lw.cv_w, lw.cv_b, st->ca_v[l], T, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
     }
   }
   return 0;
@@ -178,7 +199,7 @@ static int dit_layer_qkv(Ctx& c, int l) {
   const int d = c.d;
   const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;  // [F][6][d]: shift_sa, scale_sa, gate_sa, shift_ffn, scale_ffn, gate_ffn
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
-  RTV_TRY(linear(b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_QKV, b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
   RTV_TRY(rtv_qk_norm_rope_cache(b.qkv, b.q, st->kv_k[l], st->kv_v[l], st->kv_row_stride, st->cache_row0, c.rc, d, c.H,
                                  c.cfg->eps, lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame,
                                  c.r0, c.stream));
@@ -204,18 +225,18 @@ static int dit_layer_rest(Ctx& c, int l) {
   RTV_TRY(rtv_attn_fwd(b.q, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, b.ao, 1, rc, Lkv, H, hd,
                        0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block, st->causal_block > 0 ? q_offset : 0,
                        RTV_DTYPE_BF16, stream));
-  RTV_TRY(linear(b.ao, d, lw.o_w, lw.o_b, b.x, rc, d, 0, em + 2 * d, 6 * d, fs, r0, b.x, tc, stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_O, b.ao, d, lw.o_w, lw.o_b, b.x, rc, d, 0, em + 2 * d, 6 * d, fs, r0, b.x, tc, stream));
   // cross attention (causal_model.py:480, model.py:171-228)
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, nullptr, nullptr, 0, 0, 0, lw.norm3_w, lw.norm3_b, stream));
-  RTV_TRY(linear(b.xn, d, lw.cq_w, lw.cq_b, b.qkv, rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_CQ, b.xn, d, lw.cq_w, lw.cq_b, b.qkv, rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
   RTV_TRY(rtv_rmsnorm(b.qkv, d, b.q, d, rc, d, eps, lw.cnorm_q_w, stream));
   RTV_TRY(rtv_attn_fwd(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, rc, c.cfg->text_len, H, hd, 0, d, 0, d, 0, d, 0, d,
                        scale, 0, 0, RTV_DTYPE_BF16, stream));
-  RTV_TRY(linear(b.ao, d, lw.co_w, lw.co_b, b.x, rc, d, 0, nullptr, 0, 0, 0, b.x, tc, stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_CO, b.ao, d, lw.co_w, lw.co_b, b.x, rc, d, 0, nullptr, 0, 0, 0, b.x, tc, stream));
   // FFN (causal_model.py:482-488)
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, em + 3 * d, em + 4 * d, 6 * d, fs, r0, nullptr, nullptr, stream));
-  RTV_TRY(linear(b.xn, d, lw.ffn0_w, lw.ffn0_b, b.h, rc, c.ffn, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
-  RTV_TRY(linear(b.h, c.ffn, lw.ffn2_w, lw.ffn2_b, b.x, rc, d, 0, em + 5 * d, 6 * d, fs, r0, b.x, tc, stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_FFN0, b.xn, d, lw.ffn0_w, lw.ffn0_b, b.h, rc, c.ffn, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_FFN2, b.h, c.ffn, lw.ffn2_w, lw.ffn2_b, b.x, rc, d, 0, em + 5 * d, 6 * d, fs, r0, b.x, tc, stream));
   return 0;
 }
 
@@ -224,7 +245,7 @@ static int dit_head(Ctx& c, void* head_rows) {
   DitBuffers& b = c.b;
   const int d = c.d, n = c.cfg->out_dim * 4;
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, b.ehead + 0 * d, b.ehead + 1 * d, 2 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
-  RTV_TRY(linear(b.xn, d, c.w->head_w, c.w->head_b, (uint16_t*)head_rows + (size_t)c.r0 * n, c.rc, n, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
+  RTV_TRY(linear(c, S_HEAD, b.xn, d, c.w->head_w, c.w->head_b, (uint16_t*)head_rows + (size_t)c.r0 * n, c.rc, n, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
   return 0;
 }
 

@@ -418,3 +418,52 @@ def test_config1_320x192_native_block_and_vae():
     px = sess.generate_block()
     assert px.shape == (1, 6, 3, 192, 320) and torch.isfinite(px).all() and float(px.abs().max()) <= 1.0
     assert rel_l2(sess.all_latents.cpu(), ref) <= 5e-2
+
+
+def test_fp8_forward_matches_fp8_oracle():
+    """BASELINE config 5's weight path (release_server.py:179-182, torchao Float8DynamicActivationFloat8WeightConfig
+    PerTensor over every nn.Linear): native enable_fp8() forward vs the oracle's restatement of the same arithmetic, on a
+    denoise step at cache offset 0, the block-causal recompute pass and a second-block denoise step.  Tolerance: both
+    sides take identical quantisation decisions except where upstream bf16 rounding differs, so rel-L2 <= 3e-2 against
+    the fp8 oracle; the fp8 result must also stay within 10 % rel-L2 of the bf16 model (quantisation noise, not a bug)."""
+    from oracle import wan_oracle as wo
+    cfg, text_dim, tiny_inputs = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    w8 = dict(w)
+    w8[wo.FP8_FLAG] = True
+    lat, ctx = tiny_inputs()
+    sched = wo.FlowMatchScheduler()
+    kvc = wo.initialize_kv_cache(cfg["num_layers"], 1, 9360, cfg["num_heads"], 128, torch.bfloat16)
+    cac = wo.initialize_crossattn_cache(cfg["num_layers"], 1, cfg["num_heads"], 128, torch.bfloat16)
+    t = torch.ones([1, 3], dtype=torch.int64) * 700
+    t0 = torch.zeros([1, 3], dtype=torch.int64)
+    ref_a, _ = wo.wrapper_forward(w8, cfg, sched, lat[0], [ctx], t, kvc, cac, 0)
+    wo.reset_kv_cache(kvc)
+    ref_rc, _ = wo.wrapper_forward(w8, cfg, sched, lat[2], [ctx], t0, kvc, cac, 4680, recompute=True)
+    ref_b, _ = wo.wrapper_forward(w8, cfg, sched, lat[3], [ctx], t, kvc, cac, 4680)
+
+    outs = {}
+    for mode in ("bf16", "fp8"):
+        model, wr = _build(cfg, text_dim, w)
+        if mode == "fp8":
+            model.enable_fp8()
+        kv, ca = _caches(cfg, 9360)
+        cond = {"prompt_embeds": [ctx.to(DEV)]}
+        a, _ = wr(lat[0].to(DEV), cond, t.to(DEV), kv, ca, current_start=0)
+        for c in kv:
+            c["global_end_index"] = 0
+            c["local_end_index"] = 0
+        model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560,
+                                                                     num_frame_per_block=3)
+        rc, _ = wr(lat[2].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680)
+        model.block_mask = None
+        b, _ = wr(lat[3].to(DEV), cond, t.to(DEV), kv, ca, current_start=4680)
+        outs[mode] = [x.cpu() for x in (a, rc, b)]
+    for ours, ref in zip(outs["fp8"], (ref_a, ref_rc, ref_b)):
+        assert rel_l2(ours, ref) <= 3e-2
+    for f8, bf in zip(outs["fp8"], outs["bf16"]):
+        assert 0 < rel_l2(f8, bf) <= 0.1
+    with pytest.raises(NotImplementedError):
+        m2, _ = _build(cfg, text_dim, w)
+        m2.context_parallel = object()
+        m2.enable_fp8()

@@ -142,3 +142,29 @@ def test_config1_plumbing_320x192_one_block_one_step():
     out = ora.generate_block()
     assert out.shape == (1, 3, 16, 24, 40) and out.dtype == torch.bfloat16 and torch.isfinite(out.float()).all()
     assert ora.kv_cache[0]["global_end_index"] == 3 * 240 and ora.current_start_frame == 3
+
+
+def test_fp8_linear_restatement_properties():
+    """The fp8 nn.Linear restatement (torchao PerTensor dynamic activation x static weight, oracle/wan_oracle.fp8_linear):
+    exact on values that e4m3 represents, saturating scale at the tensor maximum, small error on Gaussian data."""
+    from oracle import wan_oracle as wo
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 256, generator=g).to(torch.bfloat16)
+    w = (torch.randn(128, 256, generator=g) * 256 ** -0.5).to(torch.bfloat16)
+    b = torch.randn(128, generator=g).to(torch.bfloat16)
+    y8 = wo.fp8_linear(x, w, b)
+    y = torch.nn.functional.linear(x.float(), w.float(), b.float())
+    assert y8.dtype == torch.bfloat16 and rel_l2(y8, y) <= 6e-2
+    # powers of two up to the scale maximum survive e4m3 exactly -> the fp8 product equals the exact one
+    xe = torch.tensor([[448.0, 1.0, -2.0, 0.5] + [0.0] * 124]).to(torch.bfloat16)
+    we = torch.eye(128).to(torch.bfloat16)
+    assert torch.equal(wo.fp8_linear(xe, we, None), xe)
+    # the flag routes every Linear of the model through it, q/k/v as ONE fused tensor
+    cfg = dict(TINY, num_layers=1)
+    wts = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    h = torch.randn(1, 8, cfg["dim"], generator=g).to(torch.bfloat16)
+    q0, k0, v0 = wo._qkv(h, wts, "blocks.0.self_attn")
+    w8 = dict(wts)
+    w8[wo.FP8_FLAG] = True
+    q8, k8, v8 = wo._qkv(h, w8, "blocks.0.self_attn")
+    assert 0 < rel_l2(q8, q0) <= 8e-2 and 0 < rel_l2(v8, v0) <= 8e-2
