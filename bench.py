@@ -23,6 +23,7 @@ MODELS = {
     "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, name="Wan2.1-T2V-1.3B arch"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md)
+MFMA_SUSTAINED_FP8_TFLOPS = 4350.0  # v_mfma_f32_32x32x64_f8f6f4 loop, random e4m3 operands (scripts/micro/fp8_mfma.hip)
 MFMA_SUSTAINED_TFLOPS = 1770.0  # measured: MFMA-only loop, random operands, clock settles at 1.78 GHz (profiles/r01_mfma_peak.txt)
 
 
@@ -104,6 +105,10 @@ def main():
     ap.add_argument("--profile-classes", default="gemm",
                     help="kernel classes bracketed with hipEvents inside the timed region: 'gemm' (the roofline kernel, "
                          "default), 'all' (diagnostic: every launch, costs a few %% of throughput) or 'none'")
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE config 5's weight path (reference enable_fp8: e4m3 weights + dynamic per-tensor e4m3 "
+                         "activations in every nn.Linear).  NOT the headline precision: the line is flagged dtype fp8 and "
+                         "carries no vs_baseline")
     ap.add_argument("--keep-first-frame", action="store_true",
                     help="GenerateParams.keep_first_frame=True: skip the per-block first-frame VAE re-encode (A/B runs)")
     ap.add_argument("--gemm-tile-cfg", type=int, default=0)
@@ -145,6 +150,10 @@ def main():
     model = CausalWanModel(dim=mc["dim"], ffn_dim=mc["ffn_dim"], num_heads=mc["num_heads"], num_layers=mc["num_layers"],
                            text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)
     model.gemm_tile_cfg = args.gemm_tile_cfg
+    if args.fp8:
+        if world > 1 and args.parallel == "cp":
+            raise SystemExit("--fp8 with context parallelism is not built (per-tensor activation scales need an all-reduce)")
+        model.enable_fp8()
     use_cp = world > 1 and args.parallel == "cp"
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
@@ -203,7 +212,7 @@ def main():
     gm = prof["gemm"]
     achieved = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     fwd_per_block = args.denoising_steps + 1
-    traffic, traffic_src = measured_traffic(args.model) if world == 1 else (None, None)
+    traffic, traffic_src = measured_traffic(args.model) if world == 1 and not args.fp8 else (None, None)
     result = {
         "metric": "frames/sec at 832x480, 4-step 14B T2V (per-step DiT latency in config)",
         "value": total_frames / elapsed,
@@ -214,8 +223,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
         "scaling": "strong" if use_cp else "weak",
-        "vs_baseline": (total_frames / elapsed) / 11.0 if args.model == "14b" and world == 1 and not args.no_vae else None,
-        "dtype": "bf16",
+        "vs_baseline": ((total_frames / elapsed) / 11.0
+                        if args.model == "14b" and world == 1 and not args.no_vae and not args.fp8 else None),
+        "dtype": "fp8 e4m3 linears (per-tensor dynamic activations, fp32 accumulation), bf16 elsewhere" if args.fp8 else "bf16",
         "data": "synthetic (random-init weights of the named architecture, N(0,1) latents/noise, N(0,1) prompt embeddings)",
         "config": {
             "workload": f"{mc['name']}, 832x480 (latent 60x104, 1560 tokens/frame), {args.denoising_steps} denoising steps, "
@@ -240,13 +250,13 @@ def main():
             "kernel": "gemm8_kernel / gemm_kernel (bf16 MFMA projection GEMMs with fused epilogues: all DiT linears)",
             "bound": "mfma",
             "achieved": achieved,
-            "peak": MFMA_PEAK_TFLOPS,
+            "peak": MFMA_PEAK_TFLOPS * (2.0 if args.fp8 else 1.0),
             "unit": "TFLOP/s",
-            "frac": achieved / MFMA_PEAK_TFLOPS,
+            "frac": achieved / (MFMA_PEAK_TFLOPS * (2.0 if args.fp8 else 1.0)),
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": gemm_algorithmic_bytes(mc),
-            "frac_of_sustained_mfma": achieved / MFMA_SUSTAINED_TFLOPS,
+            "algorithmic_bytes_per_launch": None if args.fp8 else gemm_algorithmic_bytes(mc),
+            "frac_of_sustained_mfma": achieved / (MFMA_SUSTAINED_FP8_TFLOPS if args.fp8 else MFMA_SUSTAINED_TFLOPS),
             "launches": gm["launches"],
             "avg_launch_ms": gm["ms"] / max(gm["launches"], 1),
             "attention_TFLOPs": prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12 if prof["attn"]["ms"] > 0 else None,
