@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--profile-classes", default="gemm",
                     help="kernel classes bracketed with hipEvents inside the timed region: 'gemm' (the roofline kernel, "
                          "default), 'all' (diagnostic: every launch, costs a few %% of throughput) or 'none'")
+    ap.add_argument("--hipgraph", action="store_true",
+                    help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
+                         "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
+                         "launch-gap cost, not the contract line")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5's weight path (reference enable_fp8: e4m3 weights + dynamic per-tensor e4m3 "
                          "activations in every nn.Linear).  NOT the headline precision: the line is flagged dtype fp8 and "
@@ -150,6 +154,11 @@ def main():
     model = CausalWanModel(dim=mc["dim"], ffn_dim=mc["ffn_dim"], num_heads=mc["num_heads"], num_layers=mc["num_layers"],
                            text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)
     model.gemm_tile_cfg = args.gemm_tile_cfg
+    if args.hipgraph:
+        if world > 1 and args.parallel == "cp":
+            raise SystemExit("--hipgraph covers the single-GPU forward (the context-parallel path interleaves collectives)")
+        model.use_hip_graphs = True
+        args.profile_classes = "none"
     if args.fp8:
         if world > 1 and args.parallel == "cp":
             raise SystemExit("--fp8 with context parallelism is not built (per-tensor activation scales need an all-reduce)")

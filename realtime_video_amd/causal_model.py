@@ -132,6 +132,8 @@ class CausalWanModel:
         self._tensors = {}      # name -> device tensor (keeps the memory alive)
         self._w = None          # ctypes weight table
         self._ws = {}           # (F, gh, gw) -> workspace tensor
+        self.use_hip_graphs = False   # replay each distinct forward (recompute / denoise step) from a captured hipGraph
+        self._graphs = {}
         self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps, 0)
 
     # ------------------------------------------------------------------ nn.Module-ish conveniences
@@ -389,6 +391,33 @@ class CausalWanModel:
         if self.gemm_tile_cfg in (0, 5):
             ops.ensure_gemm_workspace(u.device)
         if cp is None or cp.world == 1:
+            graph_key = None
+            if self.use_hip_graphs and not need_cross:
+                # the ~530 launches of one forward replayed as ONE hipGraph.  Everything the launch sequence
+                # depends on is part of the key (steady state has two entries: the recompute pass and the denoise step);
+                # the latent / timestep / output live in static buffers.  The first sighting of a key runs eagerly.
+                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, int(self.gemm_tile_cfg), rs,
+                             kv_cache[0]["k"].data_ptr(), kv_cache[-1]["v"].data_ptr(), crossattn_cache[0]["k"].data_ptr())
+                ent = self._graphs.get(graph_key)
+                if isinstance(ent, dict):
+                    ent["u"].copy_(u)
+                    ent["t"].copy_(tt)
+                    ent["graph"].replay()
+                    return ent["out"].clone().unsqueeze(0)
+            if graph_key is not None and self._graphs.get(graph_key) == "seen":
+                ent = {"u": u.clone(), "t": tt.clone(), "out": out, "keep": (kk_keep, kv_keep, ck_keep, cv_keep)}
+                u, tt = ent["u"], ent["t"]
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    stream = c_vp(torch.cuda.current_stream().cuda_stream)
+                    st, wsa = make((0, 0), 0)
+                    _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)
+                ent["graph"], ent["step"] = g, st
+                self._graphs[graph_key] = ent
+                g.replay()
+                return out.clone().unsqueeze(0)
+            if graph_key is not None:
+                self._graphs[graph_key] = "seen"
             st, wsa = make((0, 0), 0)
             _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)
         else:
