@@ -139,10 +139,6 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
       return launch_gemm9(p, f16, true, 3, stream);   // + split-K of the tail round
     case 71: case 72: case 73: case 74: case 75: case 76: case 77:
       return launch_gemm9(p, f16, false, tile_cfg, stream);  // timing ablations of gemm9 (results are garbage)
-    case 8:
-      return launch_gemm10(p, f16, 0, stream);     // 256x256, 4 waves x 128x128, gemm9 schedule at one wave per SIMD
-    case 81: case 82: case 83: case 87:
-      return launch_gemm10(p, f16, tile_cfg - 80, stream);  // timing ablations (results are garbage)
     case 61:
       return launch_gemm9(p, f16, true, 1, stream);   // A/B: prefetch distance 1 slab
     case 62:

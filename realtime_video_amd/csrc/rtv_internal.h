@@ -28,6 +28,5 @@ int launch_quantize_fp8(const uint16_t* x, int64_t ld, int M, int d, uint8_t* q,
                         unsigned* amax_scratch, hipStream_t stream);
 int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* a_scale, float w_scale,
                     hipStream_t stream);
-int launch_gemm10(const GemmParams& p, bool f16, int abl, hipStream_t stream);  // 256x256, 4 waves of 128x128 (gemm10.hip)  // 256x256 software-pipelined variant (gemm9.hip)
 
 }  // namespace rtv

@@ -6,11 +6,10 @@ m, n, k = 4680, 13824, 5120
 a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
 w = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
 out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-names = {8: "gemm10 full", 81: "gemm10 no DMA", 82: "gemm10 no LDS reads", 83: "gemm10 no DMA, no reads", 87: "gemm10 MFMA + waits only",
-         5: "gemm8 + split-K (default)", 6: "full", 71: "no DMA", 72: "no LDS reads", 73: "no DMA, no reads", 74: "no barriers", 75: "no DMA, no barriers",
+names = {5: "gemm8 + split-K (NL = 2)", 6: "full", 71: "no DMA", 72: "no LDS reads", 73: "no DMA, no reads", 74: "no barriers", 75: "no DMA, no barriers",
          76: "no reads, no barriers", 77: "MFMA + waits only"}
 ops.ensure_gemm_workspace('cuda')
-for cfg in (5, 6, 71, 72, 73, 77, 8, 81, 82, 83, 87):
+for cfg in (5, 6, 71, 72, 73, 74, 75, 76, 77):
     for _ in range(3):
         ops.gemm(a, w, out=out, tile_cfg=cfg)
     torch.cuda.synchronize()

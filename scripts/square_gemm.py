@@ -7,7 +7,7 @@ for n in (4096, 8192):
     a = (torch.rand(n, n, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(n, n, device="cuda") * 2 - 1).to(torch.bfloat16)
     out = torch.empty(n, n, device="cuda", dtype=torch.bfloat16)
-    for cfg in (5, 52, 7):
+    for cfg in (50, 7, 1):
         for _ in range(3):
             ops.gemm(a, w, out=out, tile_cfg=cfg)
         torch.cuda.synchronize()

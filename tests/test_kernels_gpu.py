@@ -81,7 +81,7 @@ def _gemm_ref(a, w, bias, act, gate, rows_per_frame, residual):
     return y
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 52])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 52])
 @pytest.mark.parametrize("M,N,K", [(4680, 1536, 1536), (200, 64, 256), (3, 1536, 256), (585, 4608, 1536),
                                    (4680, 256, 64)])
 def test_gemm_bias(ops, M, N, K, cfg):
