@@ -204,6 +204,23 @@ int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_
                  void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 int rtv_dit_finish(const rtv_dit_config* cfg, const rtv_dit_step* step, const void* head_rows, rtv_stream_t stream);
 
+/* Head-parallel exchange around self-attention (what the reference's usp_attn_forward does through
+ * xFuserLongContextAttention, xdit_context_parallel.py:149-190): per layer
+ *   layer_qkv_hp -> <host: all-to-all q_send -> q_all, kv_send -> this rank's cache rows [cache_row0, cache_row0+M)>
+ *   -> layer_attn_hp -> <host: all-to-all o_all -> o_recv> -> layer_rest_hp
+ * replaces layer_qkv / all-gather / layer_rest.  Needs num_heads % world == 0 and M % world == 0 (equal shards, row_begin =
+ * rank * M/world).  With gc = (num_heads/world) * 128:
+ *   q_send [world][M/world][gc], kv_send [world][M/world][2][gc] (K then V of a row), q_all / o_all [M][gc],
+ *   o_recv [world][M/world][gc]; block g of a send buffer goes to rank g, block g of o_recv came from rank g.
+ * In layer_attn_hp step->kv_k / kv_v address the heads THIS rank owns: [kv_size][num_heads/world][128], row stride
+ * kv_row_stride.  The other step fields and the remaining phases (begin, head, finish) are unchanged. */
+int rtv_dit_layer_qkv_hp(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer, int world,
+                         void* q_send, void* kv_send, void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+int rtv_dit_layer_attn_hp(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer, int world,
+                          const void* q_all, void* o_all, void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+int rtv_dit_layer_rest_hp(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer, int world,
+                          const void* o_recv, void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+
 /* ---- optional fp8 weight path (BASELINE config 5; reference: release_server.py:179-182 = torchao
  * Float8DynamicActivationFloat8WeightConfig(PerTensor) on every nn.Linear): OCP e4m3 operands, fp32 accumulation,
  *   y = bf16( (q(x) . q(W)^T) * s_x * s_w + bias ), s = max|t| / 448 over the whole tensor, q(t) = e4m3(clamp(t / s, +-448)).

@@ -69,6 +69,9 @@ _P3 = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step)]
 _lib.EXTRA_SIGNATURES["rtv_dit_begin"] = _P3 + [c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_qkv"] = _P3 + [ctypes.c_int, c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_rest"] = _P3 + [ctypes.c_int, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_layer_qkv_hp"] = _P3 + [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_layer_attn_hp"] = _P3 + [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_layer_rest_hp"] = _P3 + [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_head"] = _P3 + [c_vp, c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_finish"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Step), c_vp, c_vp]
 
@@ -292,6 +295,29 @@ class CausalWanModel:
             self._ws[key] = ws
         return ws
 
+    def kv_cache_heads(self):
+        """Heads per KV-cache row this rank needs: all of them, or num_heads / world under the context-parallel head
+        exchange (parallel.py) - the pipeline's cache manager allocates with this."""
+        cp = self.context_parallel
+        if cp is not None and getattr(cp, "world", 1) > 1 and len(cp.local_ranks()) == 1 and cp.head_exchange(self.num_heads):
+            return self.num_heads // cp.world
+        return self.num_heads
+
+    def _exchange_buffers(self, M, world, slot, device):
+        """Send / receive buffers of the head exchange (include/rtv_hip.h, rtv_dit_layer_*_hp), cached per shape."""
+        key = (M, world, slot)
+        if not hasattr(self, "_xbufs"):
+            self._xbufs = {}
+        b = self._xbufs.get(key)
+        if b is None:
+            rl, hn = M // world, self.num_heads // world
+            gc = hn * 128
+            e = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=device)
+            b = {"hn": hn, "q_send": e(world, rl, gc), "kv_send": e(world, rl, 2, gc), "q_all": e(M, gc), "o_all": e(M, gc),
+                 "o_recv": e(world, rl, gc)}
+            self._xbufs[key] = b
+        return b
+
     def _cache_window(self, kv_cache, num_new, current_start, frame_seqlen):
         """Integer bookkeeping of CausalWanSelfAttention.forward (causal_model.py:305-314 and :349-392).
         Returns (cache_row0, kv_lo, kv_hi, start_frame, causal_block) and updates every layer's indices;
@@ -380,7 +406,7 @@ class CausalWanModel:
         stream = c_vp(torch.cuda.current_stream().cuda_stream)
         cfg_p, w_p = ctypes.byref(self._cfg), ctypes.byref(self._w)
 
-        def make(rank_rows, slot):
+        def make(rank_rows, slot, kk=kk, kv=kv):
             ws = self._workspace(F, gh, gw, slot)
             ws_ptr = (ws.data_ptr() + 255) & ~255
             st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
@@ -424,15 +450,45 @@ class CausalWanModel:
             # context parallel: local rows only, ONE K/V all-gather per layer (parallel.py).  `local_ranks` is
             # [rank] in production; a single-process simulation of several ranks runs them in lockstep.
             from .parallel import shard_rows
-            parts = [make(shard_rows(M, cp.world, r), i) for i, r in enumerate(cp.local_ranks())]
+            W, H = cp.world, self.num_heads
+            heads = cp.head_exchange(H)
+            keep = []
+            if heads:
+                # head exchange: every rank's step addresses the cache heads it owns (the whole cache when it was
+                # allocated with kv_cache_heads() heads, a head slice of a full-head cache otherwise)
+                hn = H // W
+                if kv_cache[0]["k"].shape[2] not in (hn, H):
+                    raise ValueError(f"KV cache must hold {hn} (this rank's) or {H} heads, not {kv_cache[0]['k'].shape[2]}")
+                parts = []
+                for i, r in enumerate(cp.local_ranks()):
+                    h0 = 0 if kv_cache[0]["k"].shape[2] == hn else r * hn
+                    ka, kp = ptr_array([c["k"][0, :, h0:h0 + hn] for c in kv_cache])
+                    va, vp = ptr_array([c["v"][0, :, h0:h0 + hn] for c in kv_cache])
+                    keep.append((ka, va))
+                    parts.append(make(shard_rows(M, W, r), i, kp, vp))
+                bufs = [(r, self._exchange_buffers(M, W, i, u.device)) for i, r in enumerate(cp.local_ranks())]
+            else:
+                parts = [make(shard_rows(M, W, r), i) for i, r in enumerate(cp.local_ranks())]
             for st, wsa in parts:
                 _lib.call("rtv_dit_begin", cfg_p, w_p, ctypes.byref(st), *wsa)
             for l in range(L):
-                for st, wsa in parts:
-                    _lib.call("rtv_dit_layer_qkv", cfg_p, w_p, ctypes.byref(st), l, *wsa)
-                cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
-                for st, wsa in parts:
-                    _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
+                if not heads:
+                    for st, wsa in parts:
+                        _lib.call("rtv_dit_layer_qkv", cfg_p, w_p, ctypes.byref(st), l, *wsa)
+                    cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                    for st, wsa in parts:
+                        _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
+                    continue
+                for (st, wsa), (_, b) in zip(parts, bufs):
+                    _lib.call("rtv_dit_layer_qkv_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_send"].data_ptr()),
+                              c_vp(b["kv_send"].data_ptr()), *wsa)
+                cp.exchange_qkv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                for (st, wsa), (_, b) in zip(parts, bufs):
+                    _lib.call("rtv_dit_layer_attn_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_all"].data_ptr()),
+                              c_vp(b["o_all"].data_ptr()), *wsa)
+                cp.exchange_o(bufs)
+                for (st, wsa), (_, b) in zip(parts, bufs):
+                    _lib.call("rtv_dit_layer_rest_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["o_recv"].data_ptr()), *wsa)
             hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
             for st, wsa in parts:
                 _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)

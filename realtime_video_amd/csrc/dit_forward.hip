@@ -7,6 +7,12 @@
 // M = F*gh*gw tokens.  Every per-token op runs on the local rows only; the single exchange per layer is the
 // all-gather of the new K/V rows into the replicated KV cache, done by the host (RCCL via torch.distributed)
 // between rtv_dit_layer_qkv and rtv_dit_layer_rest.  rtv_dit_forward = the unsharded composition.
+//
+// Head-parallel exchange (the *_hp phases; the reference's usp_attn_forward, xdit_context_parallel.py:149-190, does the
+// same through xFuserLongContextAttention): tokens stay sharded for every per-token op, but around self-attention the
+// shard flips to heads - each rank attends ALL M query rows for its H/world heads over a KV cache that holds only those
+// heads.  Two all-to-alls per layer (q|k|v out, attention output back) move 4*(M/world)*d*(world-1)/world elements per
+// rank instead of the all-gather's 2*M*d*(world-1)/world: world/2 times less xGMI traffic.
 #include "rtv_common.h"
 #include "rtv_internal.h"
 
@@ -206,15 +212,14 @@ static int dit_layer_qkv(Ctx& c, int l) {
   return 0;
 }
 
+static int dit_after_attn(Ctx& c, int l);
+
 // ---- layer, part 2: attention over the cache window -> o-proj(+gate,+res) -> cross-attn -> FFN
 static int dit_layer_rest(Ctx& c, int l) {
-  const rtv_dit_layer_weights& lw = c.w->layers[l];
   const rtv_dit_step* st = c.st;
   DitBuffers& b = c.b;
-  const int d = c.d, H = c.H, hd = c.hd, fs = c.fs, tc = c.tc, rc = c.rc, r0 = c.r0;
+  const int d = c.d, H = c.H, hd = c.hd, rc = c.rc, r0 = c.r0;
   rtv_stream_t stream = c.stream;
-  const float eps = c.cfg->eps;
-  const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;
   const float scale = 1.0f / sqrtf((float)hd);
   const int64_t rs = st->kv_row_stride;
   const int Lkv = st->kv_hi - st->kv_lo;
@@ -225,6 +230,19 @@ static int dit_layer_rest(Ctx& c, int l) {
   RTV_TRY(rtv_attn_fwd(b.q, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, b.ao, 1, rc, Lkv, H, hd,
                        0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block, st->causal_block > 0 ? q_offset : 0,
                        RTV_DTYPE_BF16, stream));
+  return dit_after_attn(c, l);
+}
+
+// ---- layer, part 3: b.ao (self-attention output of the local rows) -> o-proj(+gate,+res) -> cross-attn -> FFN
+static int dit_after_attn(Ctx& c, int l) {
+  const rtv_dit_layer_weights& lw = c.w->layers[l];
+  const rtv_dit_step* st = c.st;
+  DitBuffers& b = c.b;
+  const int d = c.d, H = c.H, hd = c.hd, fs = c.fs, tc = c.tc, rc = c.rc, r0 = c.r0;
+  rtv_stream_t stream = c.stream;
+  const float eps = c.cfg->eps;
+  const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;
+  const float scale = 1.0f / sqrtf((float)hd);
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_O, b.ao, d, lw.o_w, lw.o_b, b.x, rc, d, 0, em + 2 * d, 6 * d, fs, r0, b.x, tc, stream));
   // cross attention (causal_model.py:480, model.py:171-228)
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, nullptr, nullptr, 0, 0, 0, lw.norm3_w, lw.norm3_b, stream));
@@ -238,6 +256,52 @@ static int dit_layer_rest(Ctx& c, int l) {
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_FFN0, b.xn, d, lw.ffn0_w, lw.ffn0_b, b.h, rc, c.ffn, RTV_ACT_GELU_TANH, nullptr, 0, 0, 0, nullptr, tc, stream));
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_FFN2, b.h, c.ffn, lw.ffn2_w, lw.ffn2_b, b.x, rc, d, 0, em + 5 * d, 6 * d, fs, r0, b.x, tc, stream));
   return 0;
+}
+
+// ---- head-parallel phases.  Exchange buffers are caller-owned (the host runs the all-to-alls on them):
+//   q_send  [world][rc][gc]       gc = (H/world)*128 columns of one head group
+//   kv_send [world][rc][2][gc]    K and V of a row adjacent, i.e. the row layout of a K/V-interleaved cache arena
+//   q_all / o_all [M][gc]         all query rows / attention output for this rank's heads
+//   o_recv  [world][rc][gc]       attention output of the local rows, one block per head group
+// In these phases step->kv_k / kv_v point at THIS RANK'S heads ([kv_size][H/world][128], row stride kv_row_stride).
+static int hp_check(Ctx& c, int world) {
+  if (world <= 1 || c.H % world) return set_error(-1, "dit: head-parallel exchange needs num_heads % world == 0");
+  if (c.M % world || c.rc != c.M / world || c.r0 % c.rc)
+    return set_error(-1, "dit: head-parallel exchange needs equal token shards (M % world == 0)");
+  return 0;
+}
+
+static int dit_layer_qkv_hp(Ctx& c, int l, int world, void* q_send, void* kv_send) {
+  RTV_TRY(hp_check(c, world));
+  const rtv_dit_layer_weights& lw = c.w->layers[l];
+  DitBuffers& b = c.b;
+  const int d = c.d, gc = d / world;
+  const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;
+  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
+  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_QKV, b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
+  return qk_norm_rope_launch(b.qkv, q_send, kv_send, (uint16_t*)kv_send + gc, 2 * gc, 0, c.rc, d, c.H, c.cfg->eps, lw.norm_q_w,
+                             lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, c.st->start_frame, c.r0, gc, (int64_t)c.rc * gc,
+                             (int64_t)c.rc * 2 * gc, c.stream);
+}
+
+static int dit_layer_attn_hp(Ctx& c, int l, int world, const void* q_all, void* o_all) {
+  RTV_TRY(hp_check(c, world));
+  const rtv_dit_step* st = c.st;
+  const int gc = c.d / world, hn = c.H / world;
+  const int64_t rs = st->kv_row_stride;
+  const int Lkv = st->kv_hi - st->kv_lo;
+  const int q_offset = st->cache_row0 - st->kv_lo;
+  const uint16_t* kc = (const uint16_t*)st->kv_k[l];
+  const uint16_t* vc = (const uint16_t*)st->kv_v[l];
+  return rtv_attn_fwd(q_all, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, o_all, 1, c.M, Lkv, hn, c.hd, 0, gc, 0,
+                      rs, 0, rs, 0, gc, 1.0f / sqrtf((float)c.hd), st->causal_block, st->causal_block > 0 ? q_offset : 0,
+                      RTV_DTYPE_BF16, c.stream);
+}
+
+static int dit_layer_rest_hp(Ctx& c, int l, int world, const void* o_recv) {
+  RTV_TRY(hp_check(c, world));
+  RTV_TRY(regroup_heads(o_recv, c.b.ao, c.rc, world, c.d / world, c.stream));
+  return dit_after_attn(c, l);
 }
 
 // ---- head on local rows (causal_model.py:512-523) -> head_rows[row_begin : row_begin+row_count)
@@ -270,6 +334,34 @@ extern "C" int rtv_dit_layer_rest(const rtv_dit_config* cfg, const rtv_dit_weigh
   RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
   if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
   return dit_layer_rest(c, layer);
+}
+
+extern "C" int rtv_dit_layer_qkv_hp(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,
+                                    int world, void* q_send, void* kv_send, void* ws, size_t ws_bytes, rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
+  if (!q_send || !kv_send) return set_error(-1, "dit: exchange buffers required");
+  return dit_layer_qkv_hp(c, layer, world, q_send, kv_send);
+}
+
+extern "C" int rtv_dit_layer_attn_hp(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,
+                                     int world, const void* q_all, void* o_all, void* ws, size_t ws_bytes,
+                                     rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
+  if (!q_all || !o_all) return set_error(-1, "dit: exchange buffers required");
+  return dit_layer_attn_hp(c, layer, world, q_all, o_all);
+}
+
+extern "C" int rtv_dit_layer_rest_hp(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,
+                                     int world, const void* o_recv, void* ws, size_t ws_bytes, rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
+  if (!o_recv) return set_error(-1, "dit: exchange buffers required");
+  return dit_layer_rest_hp(c, layer, world, o_recv);
 }
 
 extern "C" int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, void* head_rows,

@@ -153,6 +153,10 @@ struct RopeArgs {
   const bf16_t* wk;
   const float2* rope_cs;  // [1024][hd/2]
   int gh, gw, start_frame, row_offset;
+  // head-group scatter (head-parallel exchange, dit_forward.hip): group_cols > 0 sends columns [g*group_cols, (g+1)*group_cols)
+  // of local row r to q_out + g*q_group_stride + r*group_cols and k/v + g*kv_group_stride + r*cache_row_stride.
+  int group_cols;
+  int64_t q_group_stride, kv_group_stride;
 };
 
 __device__ __forceinline__ void rope8(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
@@ -208,9 +212,11 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
   const int pos_h = rem / a.gw, pos_w = rem - pos_h * a.gw;
   const int pos_f = a.start_frame + f;
 
-  bf16_t* qo = a.q_out + (size_t)row * d;
-  bf16_t* ko = a.k_cache + (size_t)(a.cache_row0 + grow) * a.cache_row_stride;
-  bf16_t* vo = a.v_cache + (size_t)(a.cache_row0 + grow) * a.cache_row_stride;
+  const int gc = a.group_cols;
+  const size_t kv_row = gc ? (size_t)row : (size_t)(a.cache_row0 + grow);
+  bf16_t* qo = a.q_out + (size_t)row * (gc ? gc : d);
+  bf16_t* ko = a.k_cache + kv_row * a.cache_row_stride;
+  bf16_t* vo = a.v_cache + kv_row * a.cache_row_stride;
 #pragma unroll
   for (int i = 0; i < EW_MAXC; ++i) {
     int c = threadIdx.x + i * EW_THREADS;
@@ -225,9 +231,11 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
       }
       rope8(q[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
       rope8(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
-      *(u32x4*)(qo + c * 8) = pack_bf16x8(q[i]);
-      *(u32x4*)(ko + c * 8) = pack_bf16x8(k[i]);
-      *(u32x4*)(vo + c * 8) = vraw[i];
+      const int g = gc ? (c * 8) / gc : 0;
+      const int col = c * 8 - g * gc;
+      *(u32x4*)(qo + g * a.q_group_stride + col) = pack_bf16x8(q[i]);
+      *(u32x4*)(ko + g * a.kv_group_stride + col) = pack_bf16x8(k[i]);
+      *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
     }
   }
 }
@@ -301,6 +309,73 @@ __global__ void unpatchify_kernel(const bf16_t* __restrict__ rows, bf16_t* __res
 
 }  // namespace rtv
 
+namespace rtv {
+// Shared launcher; group_cols == 0 is the plain cache write of the C entry below.
+int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
+                        int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
+                        const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
+                        int64_t q_group_stride, int64_t kv_group_stride, rtv_stream_t stream) {
+  if (M <= 0) return 0;
+  if (num_heads <= 0 || d % num_heads) return set_error(-1, "qk_norm_rope_cache: d % num_heads != 0");
+  const int hd = d / num_heads;
+  if (d % 8 || d > EW_THREADS * 8 * EW_MAXC || hd % 8 || cache_row_stride % 8)
+    return set_error(-1, "qk_norm_rope_cache: alignment (d, head_dim, cache stride multiples of 8; d <= 8192)");
+  if (row_offset < 0 || row_offset + M > F * gh * gw) return set_error(-1, "qk_norm_rope_cache: rows outside the F*gh*gw token grid");
+  if (start_frame < 0 || start_frame + F > 1024 || gh > 1024 || gw > 1024)
+    return set_error(-1, "qk_norm_rope_cache: position exceeds the 1024-entry RoPE table");
+  if (cache_row0 < 0) return set_error(-1, "qk_norm_rope_cache: negative cache row");
+  if (group_cols && (group_cols % hd || d % group_cols || q_group_stride % 8 || kv_group_stride % 8))
+    return set_error(-1, "qk_norm_rope_cache: head groups must be whole heads dividing d");
+  RopeArgs a;
+  a.qkv = (const bf16_t*)qkv;
+  a.q_out = (bf16_t*)q_out;
+  a.k_cache = (bf16_t*)k_cache;
+  a.v_cache = (bf16_t*)v_cache;
+  a.cache_row_stride = cache_row_stride;
+  a.cache_row0 = cache_row0;
+  a.d = d;
+  a.hd = hd;
+  a.eps = eps;
+  a.wq = (const bf16_t*)wq;
+  a.wk = (const bf16_t*)wk;
+  a.rope_cs = (const float2*)rope_cs;
+  a.gh = gh;
+  a.gw = gw;
+  a.start_frame = start_frame;
+  a.row_offset = row_offset;
+  a.group_cols = group_cols;
+  a.q_group_stride = q_group_stride;
+  a.kv_group_stride = kv_group_stride;
+  ProfScope prof(PROF_ROPE, (hipStream_t)stream, 6.0 * M * d * 2);
+  hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+  return check_launch("qk_norm_rope_cache");
+}
+
+// in [G][rows][gc]  ->  out [rows][G*gc]   (the inverse of the head-group scatter, for the attention output)
+__global__ void regroup_heads_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out, int rows, int G, int gc8) {
+  const size_t total = (size_t)rows * G * gc8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % gc8);
+    const size_t t = i / gc8;
+    const int g = (int)(t % G);
+    const size_t r = t / G;
+    out[i] = in[((size_t)g * rows + r) * gc8 + c];
+  }
+}
+
+int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rtv_stream_t stream) {
+  if (rows <= 0) return 0;
+  if (group_cols % 8) return set_error(-1, "regroup_heads: group_cols % 8 != 0");
+  const size_t total = (size_t)rows * G * (group_cols / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  ProfScope prof(PROF_MISC, (hipStream_t)stream, 2.0 * rows * G * group_cols * 2);
+  hipLaunchKernelGGL(regroup_heads_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const u32x4*)in, (u32x4*)out,
+                     rows, G, group_cols / 8);
+  return check_launch("regroup_heads");
+}
+}  // namespace rtv
+
 using namespace rtv;
 
 extern "C" {
@@ -337,35 +412,8 @@ int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_
                            int64_t cache_row_stride, int cache_row0, int M, int d, int num_heads, float eps,
                            const void* wq, const void* wk, const void* rope_cs, int F, int gh, int gw,
                            int start_frame, int row_offset, rtv_stream_t stream) {
-  if (M <= 0) return 0;
-  if (num_heads <= 0 || d % num_heads) return set_error(-1, "qk_norm_rope_cache: d % num_heads != 0");
-  const int hd = d / num_heads;
-  if (d % 8 || d > EW_THREADS * 8 * EW_MAXC || hd % 8 || cache_row_stride % 8)
-    return set_error(-1, "qk_norm_rope_cache: alignment (d, head_dim, cache stride multiples of 8; d <= 8192)");
-  if (row_offset < 0 || row_offset + M > F * gh * gw) return set_error(-1, "qk_norm_rope_cache: rows outside the F*gh*gw token grid");
-  if (start_frame < 0 || start_frame + F > 1024 || gh > 1024 || gw > 1024)
-    return set_error(-1, "qk_norm_rope_cache: position exceeds the 1024-entry RoPE table");
-  if (cache_row0 < 0) return set_error(-1, "qk_norm_rope_cache: negative cache row");
-  RopeArgs a;
-  a.qkv = (const bf16_t*)qkv;
-  a.q_out = (bf16_t*)q_out;
-  a.k_cache = (bf16_t*)k_cache;
-  a.v_cache = (bf16_t*)v_cache;
-  a.cache_row_stride = cache_row_stride;
-  a.cache_row0 = cache_row0;
-  a.d = d;
-  a.hd = hd;
-  a.eps = eps;
-  a.wq = (const bf16_t*)wq;
-  a.wk = (const bf16_t*)wk;
-  a.rope_cs = (const float2*)rope_cs;
-  a.gh = gh;
-  a.gw = gw;
-  a.start_frame = start_frame;
-  a.row_offset = row_offset;
-  ProfScope prof(PROF_ROPE, (hipStream_t)stream, 6.0 * M * d * 2);
-  hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
-  return check_launch("qk_norm_rope_cache");
+  return rtv::qk_norm_rope_launch(qkv, q_out, k_cache, v_cache, cache_row_stride, cache_row0, M, d, num_heads, eps, wq, wk,
+                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, stream);
 }
 
 int rtv_modulation_table(const void* modulation, const void* e0, void* emod, int L, int F, int J, int J0,

@@ -29,4 +29,11 @@ int launch_quantize_fp8(const uint16_t* x, int64_t ld, int M, int d, uint8_t* q,
 int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, int ldw, const float* a_scale, float w_scale,
                     hipStream_t stream);
 
+// elementwise.hip: rtv_qk_norm_rope_cache with the optional head-group scatter, and its inverse for the attention output
+int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
+                        int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
+                        const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
+                        int64_t q_group_stride, int64_t kv_group_stride, rtv_stream_t stream);
+int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rtv_stream_t stream);
+
 }  // namespace rtv

@@ -9,6 +9,14 @@ FFN, head) runs on the local shard only, and the single exchange per layer is an
 the new block's roped K and V rows into the (replicated) KV cache; queries then attend the full window
 locally.  One more all-gather returns the head output rows.  xGMI is point-to-point, so the per-layer
 message is deliberately one contiguous buffer per rank (K and V rows interleaved in the cache arena).
+
+Two exchange patterns around self-attention (`ContextParallel(exchange=...)`):
+  "rows"  - the all-gather above: KV cache replicated, 2*M*d*(w-1)/w elements received per rank and layer;
+  "heads" - what xFuserLongContextAttention does for the reference (xdit_context_parallel.py:179-184): an all-to-all
+            turns the token shard into a head shard (rank r attends ALL rows for heads [r*H/w, (r+1)*H/w) over a cache that
+            holds only those heads) and a second one turns the output back: 4*(M/w)*d*(w-1)/w elements per rank and
+            layer, i.e. w/2 times less xGMI traffic and 1/w of the cache memory.  Needs H % w == 0.
+"auto" (default) picks "heads" whenever the head count divides.
 """
 import torch
 import torch.distributed as dist
@@ -22,14 +30,31 @@ def shard_rows(M, world, rank):
     return rank * n, n
 
 
-class ContextParallel:
-    def __init__(self, group=None):
+class _ExchangeChoice:
+    exchange = "auto"
+
+    def head_exchange(self, num_heads):
+        """True when self-attention runs head-sharded (all-to-all exchange) for a model with `num_heads` heads."""
+        if self.exchange not in ("auto", "heads", "rows"):
+            raise ValueError(f"unknown exchange {self.exchange!r}")
+        if self.world == 1 or self.exchange == "rows":
+            return False
+        if num_heads % self.world:
+            if self.exchange == "heads":
+                raise ValueError(f"head exchange needs num_heads ({num_heads}) divisible by the world size ({self.world})")
+            return False
+        return True
+
+
+class ContextParallel(_ExchangeChoice):
+    def __init__(self, group=None, exchange="auto"):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
+        self.exchange = exchange
 
     def shard(self, M):
         return shard_rows(M, self.world, self.rank)
@@ -77,13 +102,58 @@ class ContextParallel:
             self.all_gather_rows_(v[row0:row0 + M])
 
 
-class SimulatedContextParallel:
+    # ---- head exchange
+    def all_to_all_(self, out, inp):
+        """out[g-th block] <- rank g's inp[rank-th block]; both contiguous with dim 0 divisible by the world size."""
+        if not out.is_contiguous() or not inp.is_contiguous() or out.numel() != inp.numel() or out.numel() % self.world:
+            raise ValueError("all_to_all_ needs contiguous, equally sized buffers divisible by the world size")
+        if self._gloo and inp.is_cuda:      # test-only route, as in all_gather_rows_
+            host_out = torch.empty(inp.numel(), dtype=inp.dtype)
+            dist.all_to_all_single(host_out, inp.reshape(-1).cpu(), group=self.group)
+            out.view(-1).copy_(host_out)
+        else:
+            dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
+        return out
+
+    def exchange_qkv(self, parts, k, v, row0, M):
+        """parts: [(rank, bufs)] of the local rank.  q_send -> q_all, kv_send -> rows [row0, row0+M) of this rank's heads of
+        one layer's K/V cache (k, v: [kv_size, hn or H, hd] views)."""
+        (rank, b), = parts
+        self.all_to_all_(b["q_all"], b["q_send"])
+        hn, hd = b["hn"], k.shape[2]
+        h0 = 0 if k.shape[1] == hn else rank * hn
+        rows = _interleaved_rows(k, v, row0, M, h0, hn)
+        if rows is not None:
+            self.all_to_all_(rows, b["kv_send"])            # straight into the cache arena
+        else:
+            tmp = self.all_to_all_(torch.empty_like(b["kv_send"]), b["kv_send"]).view(M, 2, hn, hd)
+            k[row0:row0 + M, h0:h0 + hn] = tmp[:, 0]
+            v[row0:row0 + M, h0:h0 + hn] = tmp[:, 1]
+
+    def exchange_o(self, parts):
+        (rank, b), = parts
+        self.all_to_all_(b["o_recv"], b["o_all"])
+
+
+def _interleaved_rows(k, v, row0, M, h0, hn):
+    """The [M, 2, hn*hd] view of cache rows [row0, row0+M) when K and V rows sit side by side in one arena that holds
+    exactly this rank's heads (pipeline._initialize_kv_cache) - the all-to-all then receives in place - else None."""
+    hd = k.shape[2]
+    gc = hn * hd
+    if (k.shape[1] != hn or h0 != 0 or k.stride(0) != 2 * gc or v.stride(0) != 2 * gc or k.stride(1) != hd or
+            k.stride(2) != 1 or v.data_ptr() != k.data_ptr() + gc * k.element_size()):
+        return None
+    return torch.as_strided(k, (M, 2, gc), (2 * gc, gc, 1), k.storage_offset() + row0 * 2 * gc)
+
+
+class SimulatedContextParallel(_ExchangeChoice):
     """Runs all `world` token shards inside ONE process in lockstep (test support on a single GPU): every shard's
     kernels write straight into the shared cache / head buffer, so the collectives are no-ops.  Exercises the
     sharded launch geometry (row offsets, per-frame lookups, cache row placement) of the phase API."""
 
-    def __init__(self, world):
+    def __init__(self, world, exchange="auto"):
         self.world, self.rank = world, 0
+        self.exchange = exchange
 
     def shard(self, M):
         return shard_rows(M, self.world, 0)
@@ -96,6 +166,25 @@ class SimulatedContextParallel:
 
     def gather_kv(self, k, v, row0, M):
         return None
+
+    def exchange_qkv(self, parts, k, v, row0, M):
+        """All ranks live in this process and share one full-head cache: the all-to-alls become block copies."""
+        rl = M // self.world
+        for s, bs in parts:
+            hn, hd = bs["hn"], k.shape[2]
+            qs = bs["q_send"].view(self.world, rl, hn * hd)
+            kvs = bs["kv_send"].view(self.world, rl, 2, hn, hd)
+            for g, bg in parts:
+                bg["q_all"].view(M, hn * hd)[s * rl:(s + 1) * rl] = qs[g]
+                k[row0 + s * rl:row0 + (s + 1) * rl, g * hn:(g + 1) * hn] = kvs[g][:, 0]
+                v[row0 + s * rl:row0 + (s + 1) * rl, g * hn:(g + 1) * hn] = kvs[g][:, 1]
+
+    def exchange_o(self, parts):
+        for s, bs in parts:
+            M = bs["o_all"].shape[0]
+            rl = M // self.world
+            for g, bg in parts:
+                bs["o_recv"].view(self.world, rl, -1)[g] = bg["o_all"][s * rl:(s + 1) * rl]
 
 
 class ShardedVAEDecoder:

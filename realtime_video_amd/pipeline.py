@@ -46,7 +46,9 @@ class CausalInferencePipeline:
         """causal_inference.py:279-314."""
         kv_cache_size = self.local_attn_size * self.frame_seq_length if self.local_attn_size != -1 else 32760
         cfg = self.generator.model.config
-        shape = [batch_size, kv_cache_size, cfg.num_heads, cfg.dim // cfg.num_heads]
+        model = self.generator.model
+        heads = model.kv_cache_heads() if hasattr(model, "kv_cache_heads") else cfg.num_heads
+        shape = [batch_size, kv_cache_size, heads, cfg.dim // cfg.num_heads]
         if self.kv_cache1 and list(self.kv_cache1[0]["k"].shape) == shape and self.kv_cache1[0]["k"].dtype == dtype:
             # Reset.  The reference zero_()s all L x 2 tensors (causal_inference.py:296-303; 7.7 GB of HBM writes per block
             # at 14B, SURVEY 8f-2).  The forward only ever reads rows [.., local_end_index) and writes every row of that

@@ -67,10 +67,23 @@ def _cp_block(w, x_local, e, ctx, k_cache, v_cache, row0, cp, M):
     q = wo.rms_norm(lin(h, sa + ".q"), w[sa + ".norm_q.weight"]).view(rc, H, 128)
     k = wo.rms_norm(lin(h, sa + ".k"), w[sa + ".norm_k.weight"]).view(rc, H, 128)
     v = lin(h, sa + ".v").view(rc, H, 128)
-    k_cache[0, row0 + r0:row0 + r0 + rc] = rope_local(k)
-    v_cache[0, row0 + r0:row0 + r0 + rc] = v
-    cp.gather_kv(k_cache[0], v_cache[0], row0, M)                       # the one exchange of the layer
-    out = _attn(rope_local(q).unsqueeze(0), k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0]
+    if cp.head_exchange(H):
+        # rtv_dit_layer_qkv_hp / exchange_qkv / layer_attn_hp / exchange_o / layer_rest_hp (include/rtv_hip.h): the caches
+        # passed in hold this rank's heads only
+        W, hn = cp.world, H // cp.world
+        gc = hn * 128
+        bufs = {"hn": hn, "q_send": rope_local(q).reshape(rc, W, gc).transpose(0, 1).contiguous(),
+                "kv_send": torch.stack([rope_local(k).reshape(rc, W, gc), v.reshape(rc, W, gc)], 2).transpose(0, 1).contiguous(),
+                "q_all": torch.empty(M, gc), "o_all": None, "o_recv": torch.empty(W, rc, gc)}
+        cp.exchange_qkv([(cp.rank, bufs)], k_cache[0], v_cache[0], row0, M)
+        bufs["o_all"] = _attn(bufs["q_all"].view(1, M, hn, 128), k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0].reshape(M, gc)
+        cp.exchange_o([(cp.rank, bufs)])
+        out = bufs["o_recv"].transpose(0, 1).reshape(rc, H, 128)
+    else:
+        k_cache[0, row0 + r0:row0 + r0 + rc] = rope_local(k)
+        v_cache[0, row0 + r0:row0 + r0 + rc] = v
+        cp.gather_kv(k_cache[0], v_cache[0], row0, M)                   # the one exchange of the layer
+        out = _attn(rope_local(q).unsqueeze(0), k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0]
     x = x_local + lin(out.flatten(1), sa + ".o") * em[:, 2]
     ca = pre + ".cross_attn"
     hq = wo.rms_norm(lin(wo.layer_norm(x, 1e-6, w[pre + ".norm3.weight"], w[pre + ".norm3.bias"]), ca + ".q"),
@@ -83,38 +96,46 @@ def _cp_block(w, x_local, e, ctx, k_cache, v_cache, row0, cp, M):
     return x + y * em[:, 5]
 
 
-def _worker(rank, world, port, interleaved, ret):
+def _worker(rank, world, port, interleaved, exchange, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.set_num_threads(2)
-        cp = ContextParallel()
+        cp = ContextParallel(exchange=exchange)
         cfg, w, x, e, ctx, prev_k, prev_v = _inputs()
         M = x.shape[1]
         kv_size = 20 + M
+        hc = H // world if exchange == "heads" else H          # heads held by this rank's cache
+        if exchange == "heads":
+            prev_k, prev_v = (t[:, :, rank * hc:(rank + 1) * hc] for t in (prev_k, prev_v))
         if interleaved:
-            arena = torch.zeros(1, kv_size, 2, H, 128)
+            arena = torch.zeros(1, kv_size, 2, hc, 128)
             kc, vc = arena[:, :, 0], arena[:, :, 1]
         else:
-            kc, vc = torch.zeros(1, kv_size, H, 128), torch.zeros(1, kv_size, H, 128)
+            kc, vc = torch.zeros(1, kv_size, hc, 128), torch.zeros(1, kv_size, hc, 128)
         kc[:, :20], vc[:, :20] = prev_k, prev_v
         r0, rc = cp.shard(M)
         out_local = _cp_block(w, x[0, r0:r0 + rc], e, ctx, kc, vc, 20, cp, M)
         full = torch.zeros(M, D)
         full[r0:r0 + rc] = out_local
         cp.all_gather_rows_(full)                                       # head-output style gather
+        if exchange == "heads":                                          # reassemble the head-sharded caches for the check
+            parts = [torch.empty_like(kc) for _ in range(world)], [torch.empty_like(vc) for _ in range(world)]
+            dist.all_gather(parts[0], kc.contiguous())
+            dist.all_gather(parts[1], vc.contiguous())
+            kc, vc = torch.cat(parts[0], 2), torch.cat(parts[1], 2)
         if rank == 0:
             ret["out"], ret["k"], ret["v"] = full, kc.clone(), vc.clone()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("interleaved", [True, False])
-def test_context_parallel_block_equals_unsharded(interleaved):
+@pytest.mark.parametrize("interleaved,exchange", [(True, "rows"), (False, "rows"), (True, "heads"), (False, "heads")])
+def test_context_parallel_block_equals_unsharded(interleaved, exchange):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), interleaved, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), interleaved, exchange, ret), nprocs=world, join=True)
     cfg, w, x, e, ctx, prev_k, prev_v = _inputs()
     M = x.shape[1]
     kv = {"k": torch.zeros(1, 20 + M, H, 128), "v": torch.zeros(1, 20 + M, H, 128),

@@ -63,12 +63,12 @@ def _run_session(cp):
     return [o.cpu() for o in outs] + [sess.all_latents.cpu()], pipe.kv_cache1[1]["k"].cpu()
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, exchange, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from realtime_video_amd.parallel import ContextParallel
-        outs, k = _run_session(ContextParallel())
+        outs, k = _run_session(ContextParallel(exchange=exchange))
         ret[rank] = (outs, k)
         if os.environ.get("RTV_DBG_ENC"):
             ret[f"enc{rank}"] = list(_run_session.rec)
@@ -76,13 +76,21 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_process_context_parallel_session_equals_single_process():
+@pytest.mark.parametrize("exchange", ["rows", "heads"])
+def test_two_process_context_parallel_session_equals_single_process(exchange):
+    """exchange="rows": K/V all-gather into replicated caches; "heads": all-to-all pair, every rank holding only its own
+    heads of the KV cache (allocated head-sharded by the pipeline's cache manager)."""
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), exchange, ret), nprocs=world, join=True)
     ref_outs, ref_k = _run_session(None)
+    hn = ref_k.shape[2] // world
     for rank in range(world):
         outs, k = ret[rank]
         for a, b in zip(outs, ref_outs):
             assert torch.equal(a, b), rank           # same kernels, same data: bit-identical on every rank
-        assert torch.equal(k, ref_k)
+        if exchange == "heads":
+            assert k.shape[2] == hn
+            assert torch.equal(k, ref_k[:, :, rank * hn:(rank + 1) * hn])
+        else:
+            assert torch.equal(k, ref_k)

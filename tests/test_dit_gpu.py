@@ -184,21 +184,26 @@ def test_session_block_loop_matches_oracle():
     assert pipe.kv_cache1[0]["k"].shape == (1, 9360, cfg["num_heads"], 128)
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_context_parallel_phase_api_equals_unsharded(world):
-    """Token-axis sharding (rtv_dit_begin / layer_qkv / layer_rest / head / finish with row ranges): all shards
-    run in lockstep on this one GPU and must reproduce the unsharded forward bit for bit — denoise pass at a
-    non-zero cache offset and the block-causal recompute pass."""
+@pytest.mark.parametrize("world,exchange,heads", [(2, "rows", 2), (8, "rows", 2), (2, "heads", 2), (4, "heads", 8),
+                                                  (8, "heads", 8)])
+def test_context_parallel_phase_api_equals_unsharded(world, exchange, heads):
+    """Token-axis sharding (rtv_dit_begin / layer_qkv / layer_rest / head / finish with row ranges) with either exchange
+    around self-attention - "rows": K/V all-gather into a replicated cache; "heads": the all-to-all pair of
+    rtv_dit_layer_{qkv,attn,rest}_hp, every rank attending all rows for its own heads.  All shards run in lockstep on
+    this one GPU and must reproduce the unsharded forward bit for bit - denoise pass at a non-zero cache offset and the
+    block-causal recompute pass."""
     from oracle import wan_oracle as wo
     from realtime_video_amd.parallel import SimulatedContextParallel
     cfg, text_dim, tiny_inputs = _tiny()
+    cfg.update(num_heads=heads, dim=128 * heads)
     w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
     lat, ctx = tiny_inputs()
     cond = {"prompt_embeds": [ctx.to(DEV)]}
     outs = []
-    for cp in (None, SimulatedContextParallel(world)):
+    for cp in (None, SimulatedContextParallel(world, exchange)):
         model, wr = _build(cfg, text_dim, w)
         model.context_parallel = cp
+        assert model.kv_cache_heads() == heads          # a simulation shares one full-head cache
         kv, ca = _caches(cfg, 9360)
         t = torch.ones([1, 3], dtype=torch.int64, device=DEV) * 700
         model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560,
