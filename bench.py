@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--keep-first-frame", action="store_true",
                     help="GenerateParams.keep_first_frame=True: skip the per-block first-frame VAE re-encode (A/B runs)")
     ap.add_argument("--gemm-tile-cfg", type=int, default=0)
+    ap.add_argument("--cp-exchange", default="auto", choices=["auto", "heads", "rows"],
+                    help="context-parallel exchange around self-attention: heads = all-to-all pair (head-sharded KV cache), "
+                         "rows = K/V all-gather (replicated cache); auto = heads when the head count divides")
     ap.add_argument("--parallel", default="cp", choices=["cp", "replicas"],
                     help="N>1: cp = context-parallel single stream (strong scaling, RCCL all-gather per layer); "
                          "replicas = one independent stream per GPU (weak scaling, no collective)")
@@ -166,7 +169,7 @@ def main():
     use_cp = world > 1 and args.parallel == "cp"
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
-        model.context_parallel = ContextParallel()
+        model.context_parallel = ContextParallel(exchange=args.cp_exchange)
     wr = WanDiffusionWrapper(model, timestep_shift=5.0)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
                                    generator=wr)
@@ -246,7 +249,11 @@ def main():
                     "frame through the streaming VAE encoder (release_server.py:572-575); warm-up >= 2 blocks puts the timed "
                     "blocks in that steady state",
             "parallelism": "single GPU" if world == 1 else (
-                f"cp{world}: one stream, token axis sharded {world}-way, K/V all-gather per layer over RCCL; VAE decode "
+                f"cp{world}: one stream, token axis sharded {world}-way, "
+                + ("self-attention head-sharded through two all-to-alls per layer over RCCL (KV cache holds "
+                   f"{mc['num_heads'] // world} of {mc['num_heads']} heads per rank)"
+                   if model.context_parallel.head_exchange(mc["num_heads"]) else "K/V all-gather per layer over RCCL")
+                + "; VAE decode "
                 f"sharded by output rows ({world} stripes + conv halos, one pixel all-gather per block), first-frame "
                 f"re-encode replicated" if use_cp else f"{world} independent replicas"),
             # kernel-class times exist only for the classes bracketed with events (--profile-classes; 'all' = diagnostic)

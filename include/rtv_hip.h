@@ -57,6 +57,9 @@ int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int64_t v_batch_stride, int64_t v_row_stride,
                  int64_t o_batch_stride, int64_t o_row_stride,
                  float scale, int causal_block, int q_offset, int dtype, rtv_stream_t stream);
+/* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
+ * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  A tuning knob for A/B measurements. */
+int rtv_attn_set_waves(int waves);
 
 /* ---- K4: projection GEMM with fused epilogue ---------------------------------------------
  * C[M,N] = epi(A[M,K] @ W[N,K]^T): replaces nn.Linear (causal_model.py:196-199,:246,:433-435,

@@ -7,6 +7,8 @@
 //
 // Workgroup = 8 waves, 256 query rows (32 per wave) of one head; KV tiles of 64 keys stream
 // HBM -> registers -> LDS (double buffered, issue-early / write-late), shared by the 8 waves.
+// A 4-wave / 128-row build of the same kernel serves launches whose 256-row grid cannot fill the
+// 256 CUs (the head-sharded attention of the context-parallel path: M rows x H/world heads).
 //   S^T = K . Q^T       (MFMA 32x32x16, K rows as the A operand from XOR-swizzled LDS, Q^T kept in
 //                        registers) -> every lane owns ONE query column: the softmax row reductions
 //                        are in-lane plus one exchange with lane^32.
@@ -34,12 +36,8 @@ struct AttnParams {
 
 constexpr int ATT_D = 128;
 constexpr int ATT_QW = 32;            // query rows per wave
-constexpr int ATT_WAVES = 8;
-constexpr int ATT_QT = ATT_QW * ATT_WAVES;  // 256 query rows per workgroup
 constexpr int ATT_KT = 64;            // keys per tile
 constexpr int ATT_TILE_BYTES = ATT_KT * ATT_D * 2;  // 16 KiB
-constexpr int ATT_THREADS = ATT_WAVES * 64;
-constexpr int ATT_LD_PER_THREAD = ATT_KT * 16 / ATT_THREADS;  // 16-byte chunks per thread per tile (2)
 
 template <int V>
 struct IntC {
@@ -67,8 +65,12 @@ __device__ __forceinline__ u32x2 lds_tr_read(const char* p) {
   return __builtin_bit_cast(u32x2, t);
 }
 
-template <bool F16, bool STAGGER>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) {
+template <bool F16, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
+  constexpr int ATT_QT = ATT_QW * NW;                    // query rows per workgroup (256 / 128)
+  constexpr int ATT_THREADS = NW * 64;
+  constexpr int ATT_LD_PER_THREAD = ATT_KT * 16 / ATT_THREADS;  // 16-byte chunks per thread per tile (2 / 4)
+  constexpr int ATT_RSTEP = ATT_THREADS / 16;            // tile rows between a thread's chunks (32 / 16)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // smem: K[2][16 KiB] | V[2][16 KiB]
   char* const sK = smem;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
   }
   const int ntiles = (wg_max_lim + ATT_KT - 1) / ATT_KT;
 
-  // ---- staging geometry: thread moves chunks id = tid + i*512 -> (row = id>>4 = tid>>4 + 32 i, chunk = tid&15).
+  // ---- staging geometry: thread moves chunks id = tid + i*THREADS -> (row = id>>4 = tid>>4 + RSTEP i, chunk = tid&15).
   //      Full tiles: uniform 64-bit base (SGPR, advanced per tile / per i) + one 32-bit lane offset per operand,
   //      so the loads cost no per-tile VALU address arithmetic; the ragged last tile clamps rows per lane.
   u32x4 kreg[ATT_LD_PER_THREAD], vreg[ATT_LD_PER_THREAD];
@@ -140,13 +142,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
       const char* vj = (const char*)(vb + (size_t)row0 * p.v_rs);
 #pragma unroll
       for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
-        kreg[i] = *(const u32x4*)(kj + (size_t)(i * 32) * p.k_rs * 2 + k_goff);
-        vreg[i] = *(const u32x4*)(vj + (size_t)(i * 32) * p.v_rs * 2 + v_goff);
+        kreg[i] = *(const u32x4*)(kj + (size_t)(i * ATT_RSTEP) * p.k_rs * 2 + k_goff);
+        vreg[i] = *(const u32x4*)(vj + (size_t)(i * ATT_RSTEP) * p.v_rs * 2 + v_goff);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
-        int kv = min(row0 + st_r + i * 32, p.Lkv - 1);
+        int kv = min(row0 + st_r + i * ATT_RSTEP, p.Lkv - 1);
         kreg[i] = *(const u32x4*)(kb + (size_t)kv * p.k_rs + st_c * 8);
         vreg[i] = *(const u32x4*)(vb + (size_t)kv * p.v_rs + st_c * 8);
       }
@@ -154,14 +156,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
   };
   // K: 16-byte chunk index XOR (row & 15)  -> conflict-free ds_read_b128 column reads
   // V: 64-byte group index XOR (row & 3)   -> conflict-free transpose reads
-  // (row & 15 and row & 3 do not depend on i: rows advance by 32)
+  // (row & 15 and row & 3 do not depend on i: rows advance by 32 or 16)
   char* const k_wr = sK + st_r * 256 + ((st_c ^ (st_r & 15)) << 4);
   char* const v_wr = sV + st_r * 256 + ((st_c << 4) ^ ((st_r & 3) << 6));
   auto write_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
-      *(u32x4*)(k_wr + buf * ATT_TILE_BYTES + i * 32 * 256) = kreg[i];
-      *(u32x4*)(v_wr + buf * ATT_TILE_BYTES + i * 32 * 256) = vreg[i];
+      *(u32x4*)(k_wr + buf * ATT_TILE_BYTES + i * ATT_RSTEP * 256) = kreg[i];
+      *(u32x4*)(v_wr + buf * ATT_TILE_BYTES + i * ATT_RSTEP * 256) = vreg[i];
     }
   };
 
@@ -192,18 +194,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
   // point cancels in O/l — with P <= 256 in the 16-bit MFMA operand and f32 accumulators.
   constexpr float RESCALE_SLACK = 8.f;
 
-  // STAGGER (kept for A/B, off by default): waves 4-7 run one barrier (= half a tile) behind waves 0-3 so that one
-  // wave's MFMA bursts meet its SIMD partner's softmax.  Measured on MI355X it is 2-3 % SLOWER than the plain
-  // schedule (profiles/r01_attn_variants.txt): the compiler already interleaves the exponentials of tile j with the
-  // O^T += V^T.P^T MFMAs inside each wave, and the extra barrier costs more than the phase shift gains.
-  //     interval 2j  : group 0  A(j)  = load K/V(j+1) -> regs, QK^T(j), softmax     | group 1  B(j-1)
-  //     interval 2j+1: group 0  B(j)  = PV(j), regs -> LDS tile j+1                  | group 1  A(j), regs -> LDS tile j+1
-  const int grp = STAGGER ? (wave >> 2) : 0;
-
+  // (A staggered schedule - waves 4-7 half a tile behind waves 0-3 - measured 2-3 % slower than this plain one,
+  // profiles/r01_attn_variants.txt: the compiler already interleaves the exponentials of tile j with the PV MFMAs.)
   auto tile = [&](const int j, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
     const bool has_next = (j + 1 < ntiles);
-    if (grp == 0 && has_next) load_tile(j + 1);  // in flight during the MFMAs below
+    if (has_next) load_tile(j + 1);  // in flight during the MFMAs below
 
     // ---------------- S^T = K . Q^T   (two independent accumulator chains, interleaved)
     f32x16 sacc[2];
@@ -266,12 +262,6 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
       }
     l_run += ps2[0] + ps2[1];
 
-    if (STAGGER) {
-      if (grp == 1 && has_next) write_tile(buf ^ 1);
-      __syncthreads();
-      if (grp == 1 && j + 2 < ntiles) load_tile(j + 2);
-    }
-
     // ---------------- O^T += V^T . P^T
 #pragma unroll
     for (int kbk = 0; kbk < 2; ++kbk)
@@ -287,22 +277,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
         }
       }
 
-    if (grp == 0 && has_next) write_tile(buf ^ 1);
+    if (has_next) write_tile(buf ^ 1);
     __syncthreads();
   };
 
   load_tile(0);
   write_tile(0);
   __syncthreads();
-  if (STAGGER && grp == 1) {
-    if (ntiles > 1) load_tile(1);
-    __syncthreads();
-  }
   for (int j = 0; j < ntiles; j += 2) {
     tile(j, IntC<0>{});
     if (j + 1 < ntiles) tile(j + 1, IntC<1>{});
   }
-  if (STAGGER && grp == 0) __syncthreads();  // group 0 closes the stagger (equal barrier counts)
 
   // ---------------- epilogue: O = O^T / l, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -324,6 +309,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
 }  // namespace rtv
 
 using namespace rtv;
+
+static int g_attn_waves = 0;  // 0 = by grid size
+
+extern "C" int rtv_attn_set_waves(int waves) {
+  if (waves != 0 && waves != 4 && waves != 8) return set_error(-1, "attn_set_waves: 0 (auto), 4 or 8");
+  g_attn_waves = waves;
+  return 0;
+}
 
 extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv,
                             int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
@@ -360,22 +353,34 @@ extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o
   p.scale_log2e = scale * 1.4426950408889634f;
   p.causal_block = causal_block;
   p.q_offset = q_offset;
-  p.n_qtiles = (Lq + ATT_QT - 1) / ATT_QT;
+  // 256-row workgroups unless their grid leaves most CUs idle: then 128-row ones.  Measured (MI355X, Lkv 14040, ms for 8 / 4
+  // waves): 4680 rows x 20 heads 0.90 / 0.88, x 10 heads (190 workgroups) 0.46 / 0.51, x 5 heads (95) 0.40 / 0.32,
+  // 585 rows x 40 heads (120) 0.40 / 0.34.
+  int waves = g_attn_waves;
+  if (waves == 0) waves = (int64_t)B * H * ((Lq + 255) / 256) < 160 ? 4 : 8;
+  const int qt_rows = ATT_QW * waves;
+  p.n_qtiles = (Lq + qt_rows - 1) / qt_rows;
   const int lds = 4 * ATT_TILE_BYTES;
-  static bool attr_set[2] = {false, false};
   const bool f16 = dtype == RTV_DTYPE_F16;
-  const void* kern = f16 ? (const void*)attn_fwd_kernel<true, false> : (const void*)attn_fwd_kernel<false, false>;
-  if (!attr_set[f16]) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  const void* kerns[4] = {(const void*)attn_fwd_kernel<false, 8>, (const void*)attn_fwd_kernel<true, 8>,
+                          (const void*)attn_fwd_kernel<false, 4>, (const void*)attn_fwd_kernel<true, 4>};
+  static bool attr_set[4] = {false, false, false, false};
+  const int ki = (waves == 4 ? 2 : 0) + (f16 ? 1 : 0);
+  if (!attr_set[ki]) {
+    hipError_t e = hipFuncSetAttribute(kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return set_error(e, "attn_fwd: hipFuncSetAttribute");
-    attr_set[f16] = true;
+    attr_set[ki] = true;
   }
   const int grid = B * H * p.n_qtiles;
   double kv_avg = Lkv;  // dense; block-causal work is smaller (reported as dense upper bound / 1)
   ProfScope prof(PROF_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Lq * kv_avg * ATT_D);
-  if (f16)
-    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3(grid), dim3(ATT_THREADS), lds, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<false, false>), dim3(grid), dim3(ATT_THREADS), lds, (hipStream_t)stream, p);
+  const dim3 g(grid), t(waves * 64);
+  if (waves == 4) {
+    if (f16) hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), g, t, lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), g, t, lds, (hipStream_t)stream, p);
+  } else {
+    if (f16) hipLaunchKernelGGL((attn_fwd_kernel<true, 8>), g, t, lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), g, t, lds, (hipStream_t)stream, p);
+  }
   return check_launch("attn_fwd");
 }

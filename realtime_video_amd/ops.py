@@ -58,6 +58,11 @@ def prof_read(cls):
 
 
 # --------------------------------------------------------------------------------------- attention
+def attn_set_waves(waves=0):
+    """Workgroup shape of attn_fwd: 8 (256 query rows), 4 (128 rows) or 0 = by grid size (rtv_attn_set_waves)."""
+    _lib.call("rtv_attn_set_waves", int(waves))
+
+
 def attn_fwd(q, k, v, out=None, scale=None, causal_block=0, q_offset=0):
     """softmax(scale q k^T) v.  q:[B,Lq,H,128], k/v:[B,Lkv,H,128] (strided views allowed as long as
     the last two dims are dense), returns [B,Lq,H,128] contiguous."""

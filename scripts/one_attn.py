@@ -1,5 +1,5 @@
 """Run the attention kernel a few times (for rocprofv3 --pmc passes) and print its time.
-usage: one_attn.py [Lq Lkv H] [iters]"""
+usage: one_attn.py [Lq Lkv H] [iters] [waves]      (waves: 0 auto, 4 or 8 - rtv_attn_set_waves)"""
 import os
 import sys
 
@@ -14,6 +14,8 @@ q = torch.randn(1, lq, h, 128, device="cuda").to(torch.bfloat16)
 k = torch.randn(1, lkv, h, 128, device="cuda").to(torch.bfloat16)
 v = torch.randn(1, lkv, h, 128, device="cuda").to(torch.bfloat16)
 o = torch.empty_like(q)
+waves = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+ops.attn_set_waves(waves)
 for _ in range(3):
     ops.attn_fwd(q, k, v, out=o)
 torch.cuda.synchronize()
@@ -24,4 +26,4 @@ for _ in range(iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
-print(f"attn Lq={lq} Lkv={lkv} H={h}: {ms:.3f} ms  {4.0 * lq * lkv * h * 128 / ms / 1e9:.1f} TF/s  RTV_ABL={os.environ.get('RTV_ABL', '0')}")
+print(f"attn Lq={lq} Lkv={lkv} H={h}: {ms:.3f} ms  {4.0 * lq * lkv * h * 128 / ms / 1e9:.1f} TF/s  waves={waves}")

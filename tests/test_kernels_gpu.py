@@ -319,6 +319,25 @@ def test_attention_rows_independent_of_wave_grouping(ops):
         assert torch.equal(part, full[:, off:]), off
 
 
+@pytest.mark.parametrize("causal_block", [0, 96])
+def test_attention_128_row_workgroups_equal_256_row_ones(ops, causal_block):
+    """The 4-wave build (chosen when the 256-row grid cannot fill the CUs: head-sharded attention under context
+    parallelism) computes every row exactly like the 8-wave one; ragged Lq / Lkv and the block-causal prefix included."""
+    g = torch.Generator().manual_seed(12)
+    Lq, Lkv, H = 333, 1000, 3
+    q = (torch.randn(1, Lq, H, 128, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    k = (torch.randn(1, Lkv, H, 128, generator=g) * torch.linspace(0.2, 5.0, Lkv).view(1, Lkv, 1, 1)).to(torch.bfloat16).to(DEV)
+    v = torch.randn(1, Lkv, H, 128, generator=g).to(torch.bfloat16).to(DEV)
+    outs = []
+    try:
+        for waves in (8, 4, 0):
+            ops.attn_set_waves(waves)
+            outs.append(ops.attn_fwd(q, k, v, causal_block=causal_block, q_offset=Lkv - Lq if causal_block else 0))
+    finally:
+        ops.attn_set_waves(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 # ----------------------------------------------------------------------------------------- fp8 path
 def _fp8_linear_ref(x, w, bias):
     """torchao Float8DynamicActivationFloat8WeightConfig(PerTensor) restated: per-tensor scales max|t|/448, e4m3 operands,
