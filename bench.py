@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--cp-exchange", default="auto", choices=["auto", "heads", "rows"],
                     help="context-parallel exchange around self-attention: heads = all-to-all pair (head-sharded KV cache), "
                          "rows = K/V all-gather (replicated cache); auto = heads when the head count divides")
+    ap.add_argument("--simulate-cp", type=int, default=0,
+                    help="diagnostic (INVALID as a result): run all shards of an N-way context-parallel forward in lockstep "
+                         "on this one GPU (no collectives, --no-vae implied); kernel_ms_per_block / N = one rank's compute")
     ap.add_argument("--parallel", default="cp", choices=["cp", "replicas"],
                     help="N>1: cp = context-parallel single stream (strong scaling, RCCL all-gather per layer); "
                          "replicas = one independent stream per GPU (weak scaling, no collective)")
@@ -170,6 +173,10 @@ def main():
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
         model.context_parallel = ContextParallel(exchange=args.cp_exchange)
+    if args.simulate_cp > 1:
+        from realtime_video_amd.parallel import SimulatedContextParallel
+        model.context_parallel = SimulatedContextParallel(args.simulate_cp, args.cp_exchange)
+        args.no_vae = True
     wr = WanDiffusionWrapper(model, timestep_shift=5.0)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
                                    generator=wr)

@@ -116,7 +116,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     // chip with 256x256 tiles, the 128x128 kernel (2 workgroups per CU) otherwise.  Thresholds from
     // profiles/r01_kbench_*.
     const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (!f16 && ((p.K >= 2048 && tiles256 >= 128) || tiles256 >= 640)) return launch_gemm8(p, f16, 1, stream);
+    // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
+    // along K over the idle CUs, scripts/cp_gemm_shapes.py)
+    if (!f16 && ((p.K >= 2048 && tiles256 >= 128) || tiles256 >= 640 || (p.K >= 8192 && tiles256 >= 64)))
+      return launch_gemm8(p, f16, 1, stream);
     tile_cfg = 1;
   }
   switch (tile_cfg) {

@@ -302,7 +302,7 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
   *sp = SplitArgs{T, 1, nullptr, nullptr};
   *grid = T;
   const int R = T % G;
-  if (allow_split && g_slabs && T > G && R > 0) {
+  if (allow_split && g_slabs && R > 0) {   // T < G (small M under context parallelism): every tile is a split tile
     int S = G / R;                 // the split units of the partial round still fit one round
     if (S > 8) S = 8;
     if (S > nk / 4) S = nk / 4;    // keep >= 4 K-tiles per segment

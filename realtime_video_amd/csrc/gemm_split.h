@@ -2,7 +2,7 @@
 //
 // T tiles on G CUs run as floor(T/G) full rounds plus R = T % G tiles; those R tiles would keep the chip at R/G
 // occupancy for a whole tile time.  Instead each of them is cut along K into S segments ("units", S = min(8, G/R)),
-// so the tail round runs R*S workgroups for 1/S of a tile time.  Partial accumulators go to an fp32 slab in a
+// so the tail round runs R*S workgroups for 1/S of a tile time (with T < G every tile is a tail tile).  Partial accumulators go to an fp32 slab in a
 // caller-provided workspace (rtv_gemm_set_workspace); the last arriver of a tile (agent-scope release / acquire around
 // an arrival counter, no spinning) adds the other slabs to its registers, resets the counter and runs the fused epilogue.
 #pragma once
