@@ -149,6 +149,11 @@ def initialize_crossattn_cache(num_layers, batch_size, num_heads, head_dim, dtyp
 # DiT block
 # ------------------------------------------------------------------------------------------------
 FP8_FLAG = "__fp8__"   # weights[FP8_FLAG] = True switches every nn.Linear to the fp8 restatement below
+# weights[FP8_ROW_SHARDS] = (world, M): under sequence parallelism every rank quantises the activation tensor IT holds
+# (M/world contiguous token rows) with its own dynamic per-tensor scale - torchao's dynamic quantisation runs inside each
+# rank's nn.Linear and knows nothing of the other shards.  Applies to the linears fed with the M token rows; the time / text
+# MLPs see whole (replicated) tensors.
+FP8_ROW_SHARDS = "__fp8_row_shards__"
 _FP8_MAX = 448.0
 
 
@@ -159,13 +164,16 @@ def _fp8_scale(t):
     return t.detach().float().abs().max().clamp(min=1e-12) * inv.to(t.device)
 
 
-def fp8_linear(x, weight, bias):
+def fp8_linear(x, weight, bias, shards=1):
     """nn.Linear under the reference's `enable_fp8` (release_server.py:179-182):
     torchao.quantize_(transformer, Float8DynamicActivationFloat8WeightConfig(granularity=PerTensor())).  torchao is not
     part of the reference tree (third-party, unpinned): this restates its published algorithm - dynamic per-tensor
     activation scale, static per-tensor weight scale, e4m3 (OCP, saturating at 448, round-to-nearest-even) operands,
     fp32 accumulation and bias inside torch._scaled_mm, output in the activation dtype.  PARITY UNPINNED for this mode:
-    no golden from the real torchao can be minted offline."""
+    no golden from the real torchao can be minted offline.  shards > 1: the rows (dim -2) are quantised in that many
+    contiguous chunks, each with its own scale (FP8_ROW_SHARDS)."""
+    if shards > 1:
+        return torch.cat([fp8_linear(c, weight, bias) for c in x.chunk(shards, dim=-2)], dim=-2)
     sx, sw = _fp8_scale(x), _fp8_scale(weight)
     xq = (x.float() / sx).clamp(-_FP8_MAX, _FP8_MAX).to(torch.float8_e4m3fn).float()
     wq = (weight.float() / sw).clamp(-_FP8_MAX, _FP8_MAX).to(torch.float8_e4m3fn).float()
@@ -175,9 +183,14 @@ def fp8_linear(x, weight, bias):
     return y.to(x.dtype)
 
 
+def _fp8_shards(w, x):
+    world, rows = w.get(FP8_ROW_SHARDS, (1, 0))
+    return world if x.dim() >= 2 and x.shape[-2] == rows else 1
+
+
 def _linear(w, x, weight, bias):
     if w.get(FP8_FLAG):
-        return fp8_linear(x, weight, bias)
+        return fp8_linear(x, weight, bias, _fp8_shards(w, x))
     return F.linear(x, weight, bias)
 
 
@@ -192,7 +205,7 @@ def _qkv(x, w, pre):
         return _lin(x, w, pre + ".q"), _lin(x, w, pre + ".k"), _lin(x, w, pre + ".v")
     wq = torch.cat([w[pre + ".q.weight"], w[pre + ".k.weight"], w[pre + ".v.weight"]])
     bq = torch.cat([w[pre + ".q.bias"], w[pre + ".k.bias"], w[pre + ".v.bias"]])
-    return fp8_linear(x, wq, bq).chunk(3, dim=-1)
+    return fp8_linear(x, wq, bq, _fp8_shards(w, x)).chunk(3, dim=-1)
 
 
 def self_attention(w, pre, x, grid, freqs, num_heads, kv_cache, current_start, recompute,

@@ -207,7 +207,9 @@ class CausalWanModel:
         Float8DynamicActivationFloat8WeightConfig(PerTensor) over every nn.Linear, after fuse_projections): weights become
         e4m3 with one scale per tensor (max|W| / 448), activations are quantised per call inside the forward
         (rtv_quantize_fp8), products accumulate in fp32 (rtv_gemm_fp8).  The Conv3d patch embedding is not an nn.Linear and
-        stays bf16.  Call after load_state_dict / init_random_weights; the bf16 copies of the quantised weights are freed."""
+        stays bf16.  Call after load_state_dict / init_random_weights; the bf16 copies of the quantised weights are freed.
+        Under context parallelism every rank quantises the token rows it holds with its own scale (a per-rank torchao
+        linear does exactly that), so the sharded fp8 forward equals the unsharded one up to quantisation noise only."""
         if self._w is None:
             raise RuntimeError("load weights before enable_fp8()")
         if self._cfg.use_fp8:
@@ -215,8 +217,6 @@ class CausalWanModel:
         for k in (self.dim, self.ffn_dim, self.text_dim, self.freq_dim):
             if k % 128:
                 raise ValueError("enable_fp8: every Linear input width must be a multiple of 128")
-        if self.context_parallel is not None:
-            raise NotImplementedError("fp8 with context parallelism needs an all-reduce of the per-tensor activation scales")
         scales = (ctypes.c_float * (len(_FP8_TOP) + len(_FP8_LAYER) * self.num_layers))()
 
         def quant(key):

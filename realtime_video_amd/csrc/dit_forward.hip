@@ -156,7 +156,7 @@ static int linear(Ctx& c, int sidx, const void* a, int K, const void* w, const v
   if (!c.cfg->use_fp8 || sidx < 0)
     return rtv_gemm(a, K, w, K, out, N, M, N, K, bias, act, gate, gate_stride, rpf, row_off, res, N, RTV_DTYPE_BF16, cfg, s);
   if (!c.w->fp8_scales) return set_error(-1, "dit: use_fp8 needs rtv_dit_weights.fp8_scales");
-  if (c.rc != c.M) return set_error(-1, "dit: the fp8 path is not token-sharded yet (per-tensor activation scales need an all-reduce)");
+  // token-sharded calls quantise the rows this rank holds with their own scale - what a per-rank torchao linear does
   if (rtv_quantize_fp8(a, K, M, K, c.b.q8, K, c.b.fscale, c.b.fscale + 1, s)) return -1;
   return rtv_gemm_fp8(c.b.q8, K, w, K, c.b.fscale, c.w->fp8_scales[sidx], out, N, M, N, K, bias, act, gate, gate_stride, rpf,
                       row_off, res, N, s);
