@@ -195,7 +195,22 @@ def main():
     n_blocks = args.warmup + args.steps
     params = GenerateParams(prompt="synthetic", seed=42, kv_cache_num_frames=args.kv_cache_num_frames,
                             num_blocks=n_blocks, num_denoising_steps=args.denoising_steps, keep_first_frame=keep_first)
-    sess = GenerationSession(params, models, device=dev)
+    # frame delivery (release_server.py:978-991): every block's pixels go to pinned host memory as rgb8 on the download
+    # stream (rank 0 under context parallelism, every rank for replicas); the previous block's frames are fetched while
+    # the next block runs, the last ones before the clock stops.
+    downloader = None
+    if vae is not None and (rank == 0 or not use_cp):
+        from realtime_video_amd.frames import FrameDownloader
+        downloader = FrameDownloader(dev, slots=2)
+    tickets = []
+
+    def deliver(pixels, frame_ids, event):
+        if downloader is not None:
+            if tickets:
+                downloader.fetch(tickets.pop())
+            tickets.append(downloader(pixels, frame_ids, event))
+
+    sess = GenerationSession(params, models, frame_callback=deliver, device=dev)
 
     def barrier():
         if world > 1:
@@ -213,6 +228,8 @@ def main():
     for _ in range(args.steps):
         out = sess.generate_block()
         frames += 12
+    if tickets:
+        downloader.fetch(tickets.pop())
     barrier()
     elapsed = time.perf_counter() - t0
     ops.prof_enable(False)
@@ -249,6 +266,8 @@ def main():
                         f"kv_cache_num_frames={args.kv_cache_num_frames}, 3 latent frames (12 pixel frames) per block, "
                         f"KV-recompute forward every block, first-frame VAE re-encode every block, streaming VAE decode {'OFF (INVALID: diagnostic run)' if args.no_vae else 'on (fp16)'}",
             "model": args.model,
+            "frame_delivery": None if args.no_vae else "rgb8 [T,H,W,3] in pinned host memory per block (GPU-side conversion + async "
+                                                       "copy on a download stream), inside the timed region",
             "keep_first_frame": keep_first,
             "note": "reference default keep_first_frame=False: from block 2 on every block re-encodes the first context "
                     "frame through the streaming VAE encoder (release_server.py:572-575); warm-up >= 2 blocks puts the timed "

@@ -293,6 +293,11 @@ int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, i
 /* z: fp16 [T][16][h][w] latents; pixels: float32 [T'][3][8h][8w] in [-1,1], T' = 4T (4T-3 when first). */
 int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first,
                    void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
+/* Output side of the decoder (the frame path of release_server.py:978-991 + :972): pixels float32 [T][3][H][W] in
+ * [-1,1] -> rgb8 [T][H][W][3] = u8(trunc(clamp((x + 1) * 0.5, 0, 1) * 255)) - the bytes the reference hands to the JPEG encoder
+ * (host-side add_(1).mul_(0.5).clamp_(0,1), then torchvision to_pil_image's mul(255).byte()) - computed on the GPU so that
+ * the device-to-host copy moves 1 byte per sample instead of 4.  H*W % 4 == 0. */
+int rtv_pixels_to_rgb8(const void* pixels, void* rgb8, int T, int H, int W, rtv_stream_t stream);
 /* Spatially sharded decode (multi-GPU, SURVEY 8e "VAE decode: shard by output rows with halo"): produce only pixel rows
  * [row0, row1) of every frame -> pixels float32 [T'][3][row1-row0][8w], bit-identical to those rows of rtv_vae_decode.
  * Stage 0 (latent resolution, global mid-block attention) runs on the whole image; stages 1-3 run on row windows with

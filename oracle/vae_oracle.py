@@ -357,3 +357,15 @@ def make_vae_encoder_weights(seed=1, dtype=torch.float32):
     gamma("encoder.head.0.gamma", 384, 3)
     conv("conv1", 32, 32, 1, 1, 1)
     return {k: v.to(dtype) for k, v in w.items()}
+
+
+# ----------------------------------------------------------------------------------------- frame output format
+def frames_to_rgb8(pixels):
+    """The bytes the reference's frame path hands to the JPEG encoder, from the decoder's float pixels [.., 3, H, W] in
+    [-1, 1]: release_server.py:980-984 (`cpu_tensor.add_(1.0).mul_(0.5).clamp_(0.0, 1.0)` on the pinned host copy) followed
+    by `TF.to_pil_image(frames[0, idx], "RGB")` (:972).  torchvision is third-party and not in the reference tree; its
+    published to_pil_image converts a float tensor with `pic.mul(255).byte()` (truncation) and lays it out H x W x C.
+    Returns uint8 [.., H, W, 3]."""
+    x = pixels.detach().float().cpu().clone()
+    x = x.add_(1.0).mul_(0.5).clamp_(0.0, 1.0)
+    return x.mul(255).byte().movedim(-3, -1).contiguous()

@@ -40,6 +40,7 @@ SIGNATURES = {
     "rtv_sinusoidal_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
     "rtv_patchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "rtv_unpatchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_pixels_to_rgb8": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "rtv_gemm_set_workspace": [c_vp, ctypes.c_size_t],
     "rtv_probe_mfma": [c_vp, c_vp, c_vp, c_vp],
     "rtv_probe_tr": [c_vp, c_vp, c_int, c_int, c_vp],

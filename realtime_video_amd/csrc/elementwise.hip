@@ -363,6 +363,36 @@ __global__ void regroup_heads_kernel(const u32x4* __restrict__ in, u32x4* __rest
   }
 }
 
+// pixels fp32 [T][3][H][W] in [-1,1]  ->  rgb8 [T][H][W][3]: u8(trunc(clamp((x + 1) * 0.5, 0, 1) * 255)), the arithmetic of the
+// reference's frame path (release_server.py:984 `add_(1.0).mul_(0.5).clamp_(0.0, 1.0)` on the host copy, then
+// torchvision to_pil_image = `mul(255).byte()`, :972).  One thread = 4 pixels: 3 float4 plane reads, 12 contiguous bytes out.
+__global__ void pixels_to_rgb8_kernel(const float* __restrict__ px, uint8_t* __restrict__ out, int T, size_t hw) {
+  const size_t quads = hw >> 2;
+  const size_t total = (size_t)T * quads;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = i / quads, q = i - t * quads;
+    const float* base = px + t * 3 * hw + q * 4;
+    float4 c[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) c[ch] = *(const float4*)(base + ch * hw);
+    uint8_t b[12];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float v[4] = {c[ch].x, c[ch].y, c[ch].z, c[ch].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float y = __fmul_rn(__fadd_rn(v[k], 1.0f), 0.5f);
+        y = fminf(fmaxf(y, 0.0f), 1.0f);
+        b[k * 3 + ch] = (uint8_t)(int)__fmul_rn(y, 255.0f);   // y is NaN-free after the clamp only if the input is; NaN -> 0
+      }
+    }
+    uint32_t* o = (uint32_t*)(out + (t * hw + q * 4) * 3);
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      o[w] = (uint32_t)b[4 * w] | ((uint32_t)b[4 * w + 1] << 8) | ((uint32_t)b[4 * w + 2] << 16) | ((uint32_t)b[4 * w + 3] << 24);
+  }
+}
+
 int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rtv_stream_t stream) {
   if (rows <= 0) return 0;
   if (group_cols % 8) return set_error(-1, "regroup_heads: group_cols % 8 != 0");
@@ -406,6 +436,21 @@ int rtv_rmsnorm(const void* x, int ldx, void* out, int ldo, int M, int d, float 
   hipLaunchKernelGGL(rmsnorm_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, (const bf16_t*)x,
                      ldx, (bf16_t*)out, ldo, d, eps, (const bf16_t*)weight);
   return check_launch("rmsnorm");
+}
+
+int rtv_pixels_to_rgb8(const void* pixels, void* rgb8, int T, int H, int W, rtv_stream_t stream) {
+  if (T <= 0 || H <= 0 || W <= 0) return 0;
+  if (!pixels || !rgb8) return set_error(-1, "pixels_to_rgb8: null argument");
+  const size_t hw = (size_t)H * W;
+  if (hw % 4 || ((uintptr_t)pixels & 15) || ((uintptr_t)rgb8 & 3))
+    return set_error(-1, "pixels_to_rgb8: H*W must be a multiple of 4, pixels 16-byte and rgb8 4-byte aligned");
+  const size_t total = (size_t)T * (hw / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  ProfScope prof(PROF_MISC, (hipStream_t)stream, (double)T * hw * 15.0);
+  hipLaunchKernelGGL(pixels_to_rgb8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)pixels,
+                     (uint8_t*)rgb8, T, hw);
+  return check_launch("pixels_to_rgb8");
 }
 
 int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_cache,

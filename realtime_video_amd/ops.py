@@ -238,3 +238,20 @@ def unpatchify(rows, C, F, gh, gw):
     out = torch.empty((C, F, 2 * gh, 2 * gw), dtype=rows.dtype, device=rows.device)
     _lib.call("rtv_unpatchify", _ptr(rows), _ptr(out), C, F, gh, gw, _stream())
     return out
+
+
+def pixels_to_rgb8(pixels, out=None):
+    """Decoder pixels float32 [..., 3, H, W] in [-1, 1] -> uint8 [..., H, W, 3] (rtv_pixels_to_rgb8): the reference's
+    host-side normalisation + to_pil_image byte conversion (release_server.py:984, :972) done on the GPU."""
+    _gpu(pixels)
+    if pixels.dtype != torch.float32 or pixels.shape[-3] != 3 or not pixels.is_contiguous():
+        raise ValueError("pixels_to_rgb8 expects contiguous float32 [..., 3, H, W]")
+    H, W = pixels.shape[-2:]
+    T = pixels.numel() // (3 * H * W)
+    shape = tuple(pixels.shape[:-3]) + (H, W, 3)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8, device=pixels.device)
+    elif out.shape != shape or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise ValueError("pixels_to_rgb8: out must be contiguous uint8 [..., H, W, 3]")
+    _lib.call("rtv_pixels_to_rgb8", _ptr(pixels), _ptr(out), T, H, W, _stream())
+    return out

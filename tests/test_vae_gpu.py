@@ -254,3 +254,51 @@ def test_gather_row_stripes_single_process():
     cp = SimulatedContextParallel(1)
     x = torch.randn(2, 3, 16, 8, device=DEV)
     assert torch.equal(gather_row_stripes(cp, x, 16), x)
+
+
+# ----------------------------------------------------------------------------------------- frame output format (8f-3)
+def _special_pixels(T=3, H=48, W=64, seed=21):
+    g = torch.Generator().manual_seed(seed)
+    px = torch.randn(T, 3, H, W, generator=g) * 0.8
+    flat = px.view(-1)
+    ks = torch.arange(256, dtype=torch.float32)
+    flat[:256] = ks / 255.0 * 2.0 - 1.0                      # values that land on (or next to) the k/255 boundaries
+    flat[256:512] = torch.nextafter(flat[:256], torch.tensor(2.0))
+    flat[512:768] = torch.nextafter(flat[:256], torch.tensor(-2.0))
+    flat[768:776] = torch.tensor([-1.0, 1.0, 0.0, -0.0, 5.0, -5.0, 1.0000001, -1.0000001])
+    return px
+
+
+def test_pixels_to_rgb8_is_bit_exact_with_the_reference_frame_arithmetic():
+    """rtv_pixels_to_rgb8 vs the oracle's restatement of release_server.py:984 + to_pil_image (bytes must be identical:
+    they are what the JPEG encoder sees)."""
+    from oracle import vae_oracle as vo
+    from realtime_video_amd import ops
+    px = _special_pixels()
+    out = ops.pixels_to_rgb8(px.to(DEV))
+    assert out.shape == (3, 48, 64, 3) and out.dtype == torch.uint8
+    assert torch.equal(out.cpu(), vo.frames_to_rgb8(px))
+    with pytest.raises(ValueError):
+        ops.pixels_to_rgb8(px.to(DEV).half())
+
+
+def test_frame_downloader_matches_reference_callback():
+    """FrameDownloader as the session's frame_callback (pixels, frame_ids, event): pinned uint8 frames, one ticket per
+    block, slots reused round-robin."""
+    from oracle import vae_oracle as vo
+    from realtime_video_amd.frames import FrameDownloader
+    dl = FrameDownloader(DEV, slots=2)
+    blocks = [_special_pixels(T=t, seed=s) for t, s in ((9, 1), (12, 2), (12, 3))]
+    tickets = []
+    for i, px in enumerate(blocks):
+        gpu = (px.to(DEV) * 1.0).unsqueeze(0)                 # produced on the current stream
+        ev = torch.cuda.Event()
+        ev.record()
+        tickets.append(dl(gpu, [f"id{i}"], ev))
+        if i >= 1:                                            # 2 slots: the previous ticket is still held
+            got = dl.fetch(tickets[i - 1])
+            assert got.is_pinned() and torch.equal(got, vo.frames_to_rgb8(blocks[i - 1]))
+    assert torch.equal(dl.fetch(tickets[-1]), vo.frames_to_rgb8(blocks[-1]))
+    assert dl.frame_ids(tickets[-1]) == ["id2"]
+    with pytest.raises(KeyError):
+        dl.fetch(tickets[0])                                  # slot already reused

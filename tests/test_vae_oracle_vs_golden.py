@@ -62,3 +62,15 @@ def test_encoder_conv_inventory():
     specs = vo.encoder_conv_specs()
     kinds = [k for _, k, _, _ in specs]
     assert kinds.count("c3") == 22 and kinds.count("d2") == 3 and kinds.count("t3") == 2 and kinds.count("c1") == 2
+
+
+def test_frames_to_rgb8_known_values():
+    """Frame output format (release_server.py:984 + to_pil_image): u8(trunc(clamp((x+1)/2, 0, 1) * 255)), H x W x C."""
+    from oracle import vae_oracle as vo
+    x = torch.tensor([-1.0, 1.0, 0.0, 5.0, -5.0, 0.5, -0.5, 1 / 255.0]).view(1, 1, 8).repeat(3, 1, 1)   # [3, 1, 8]
+    x[1] = -x[1]
+    out = vo.frames_to_rgb8(x)
+    assert out.shape == (1, 8, 3) and out.dtype == torch.uint8
+    assert out[0, :, 0].tolist() == [0, 255, 127, 255, 0, 191, 63, 128]
+    assert out[0, :, 1].tolist() == [255, 0, 127, 0, 255, 63, 191, 127]
+    assert torch.equal(out[0, :, 2], out[0, :, 0])
