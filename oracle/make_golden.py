@@ -212,11 +212,37 @@ def golden_vae_encoder(ref):
     print("vae_encoder.pt", [tuple(m.shape) for m in out["mu"]], sum(c is not None for c in cache), "cache slots")
 
 
+def golden_t5():
+    """Text encoder: the reference's own T5Encoder (wan/modules/t5.py:267-313, shared_pos=False like umt5_xxl,
+    float32 like WanTextEncoder) at tiny dims with head_dim 64, two prompts of 29 and 48 tokens in a 48-slot window, plus
+    the zeroing of the padding rows (wan_wrapper.py:52-53)."""
+    from oracle import t5_oracle as to
+    t5 = ref_shim.load_t5()
+    cfg = dict(to.TINY_T5)
+    w = to.make_t5_weights(cfg, seed=0)
+    model = t5.T5Encoder(vocab=cfg["vocab"], dim=cfg["dim"], dim_attn=cfg["dim_attn"], dim_ffn=cfg["dim_ffn"],
+                         num_heads=cfg["num_heads"], num_layers=cfg["num_layers"], num_buckets=cfg["num_buckets"],
+                         shared_pos=False, dropout=0.1).eval()
+    assert set(model.state_dict()) == set(w), sorted(set(model.state_dict()) ^ set(w))[:8]
+    model.load_state_dict(w)
+    ids, mask = to.t5_inputs(cfg)
+    with torch.inference_mode():
+        ctx = model(ids, mask).clone()
+        raw = ctx.clone()
+        for u, v in zip(ctx, mask.gt(0).sum(dim=1)):
+            u[v:] = 0.0
+        bias = model.blocks[1].pos_embedding(48, 48).clone()
+    out = {"ids": ids, "mask": mask, "context_raw": raw, "prompt_embeds": ctx, "pos_bias_block1": bias,
+           "weights_checksum": float(sum(v.double().abs().sum() for v in w.values()))}
+    torch.save(out, os.path.join(OUT, "t5_encoder.pt"))
+    print("t5_encoder.pt", tuple(ctx.shape), float(ctx.abs().mean()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -227,3 +253,5 @@ if __name__ == "__main__":
         golden_vae(ref)
     if "vae_enc" in which:
         golden_vae_encoder(ref)
+    if "t5" in which:
+        golden_t5()

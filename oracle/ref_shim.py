@@ -125,3 +125,26 @@ def build_reference_wrapper(ref, model, shift=5.0):
     wr.scheduler.set_timesteps(1000, training=True)
     wr.seq_len = 32760
     return wr
+
+
+def load_t5():
+    """The reference's real wan/modules/t5.py (load() stubs it because importing it evaluates
+    `torch.cuda.current_device()` as a default argument, t5.py:476).  Imported under another module name inside the
+    `wan.modules` package, with that call patched for the duration of the import; its `.tokenizers` import resolves to
+    the stub (ftfy is not installed)."""
+    import importlib.util
+    load()
+    name = "wan.modules.t5_reference"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "wan", "modules", "t5.py"))
+    mod = importlib.util.module_from_spec(spec)
+    mod.__package__ = "wan.modules"
+    sys.modules[name] = mod
+    real = torch.cuda.current_device
+    torch.cuda.current_device = lambda: 0
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        torch.cuda.current_device = real
+    return mod

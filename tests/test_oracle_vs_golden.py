@@ -168,3 +168,28 @@ def test_fp8_linear_restatement_properties():
     w8[wo.FP8_FLAG] = True
     q8, k8, v8 = wo._qkv(h, w8, "blocks.0.self_attn")
     assert 0 < rel_l2(q8, q0) <= 8e-2 and 0 < rel_l2(v8, v0) <= 8e-2
+
+
+def test_t5_encoder_oracle_matches_reference_golden(golden):
+    """oracle/t5_oracle (text encoder) vs the golden minted from the reference's T5Encoder + the padding-row
+    zeroing of WanTextEncoder: float32 on both sides, same op order -> tight tolerance."""
+    from oracle import t5_oracle as to
+    gold = golden("t5_encoder.pt")
+    cfg = dict(to.TINY_T5)
+    w = to.make_t5_weights(cfg, seed=0)
+    assert abs(float(sum(v.double().abs().sum() for v in w.values())) - gold["weights_checksum"]) < 1e-6
+    ids, mask = to.t5_inputs(cfg)
+    assert torch.equal(ids, gold["ids"]) and torch.equal(mask, gold["mask"])
+    bias = to.relative_bias(w["blocks.1.pos_embedding.embedding.weight"], 48, 48)
+    assert torch.equal(bias, gold["pos_bias_block1"])
+    assert torch.allclose(to.encoder(w, ids, mask, cfg), gold["context_raw"], atol=2e-5, rtol=1e-5)
+    out = to.text_encoder_forward(w, ids, mask, cfg)["prompt_embeds"]
+    assert torch.allclose(out, gold["prompt_embeds"], atol=2e-5, rtol=1e-5)
+    assert float(out[0, 29:].abs().max()) == 0.0 and float(out[0, 28].abs().max()) > 0
+
+
+def test_t5_relative_position_buckets_known_values():
+    """Bidirectional 32-bucket rule (t5.py:238-265): 16 buckets per direction, exact below 8, log-spaced up to 128."""
+    from oracle import t5_oracle as to
+    rel = torch.tensor([0, 1, 7, 8, 11, 12, 15, 16, 64, 127, 128, 500, -1, -7, -8, -127, -128, -511])
+    assert to.relative_position_bucket(rel).tolist() == [0, 17, 23, 24, 24, 25, 25, 26, 30, 31, 31, 31, 1, 7, 8, 15, 15, 15]
