@@ -339,6 +339,37 @@ int rtv_probe_mfma(const void* A /*[32][16] bf16*/, const void* B /*[16][32] bf1
 int rtv_probe_tr(const void* V /*[64][128] bf16*/, void* out /*[4][64][8] bf16*/, int kbk, int s,
                  rtv_stream_t stream);
 
+/* ---- text encoder: the UMT5-XXL encoder of wan/modules/t5.py:267-313 as WanTextEncoder runs it
+ * (utils/wan_wrapper.py:20-56), from token ids to prompt embeddings; head_dim 64, no attention scaling, per-layer relative
+ * position bias (shared_pos=False), gated-GELU feed-forward, T5LayerNorm.  All linears are bias-free; weights bf16 (the
+ * released checkpoint is bf16; the reference up-casts it to float32), residual stream / norms / softmax float32. */
+typedef struct {
+  int vocab, dim, dim_attn, dim_ffn, num_heads, num_layers;
+  float eps;                      /* 1e-6 */
+} rtv_t5_config;
+typedef struct {
+  const void* norm1_w;            /* bf16 [dim] */
+  const void* qk_w;               /* bf16 [2*dim_attn][dim]: attn.q.weight rows, then attn.k.weight rows */
+  const void* v_w;                /* bf16 [dim_attn][dim] */
+  const void* o_w;                /* bf16 [dim][dim_attn] */
+  const void* norm2_w;            /* bf16 [dim] */
+  const void* gate_fc1_w;         /* bf16 [2*dim_ffn][dim]: ffn.gate.0.weight rows, then ffn.fc1.weight rows */
+  const void* fc2_w;              /* bf16 [dim][dim_ffn] */
+  const void* pos_bias;           /* float32 [num_heads][2*max_len-1]: pos_embedding.embedding.weight[bucket(r)][h] at index
+                                     r + max_len - 1, r = key - query (T5RelativeEmbedding, t5.py:225-265) */
+} rtv_t5_layer_weights;
+typedef struct {
+  const void* token_embedding;    /* bf16 [vocab][dim] */
+  const void* final_norm_w;       /* bf16 [dim] */
+  const rtv_t5_layer_weights* layers;   /* host array [num_layers] */
+  int max_len;                    /* length the pos_bias tables were built for (512) */
+} rtv_t5_weights;
+size_t rtv_t5_workspace_bytes(const rtv_t5_config* cfg, int seq_len);
+/* ids: device int32 [seq_len] (the prompt's tokens incl. </s>); out: float32 [out_rows][dim] - rows < seq_len hold the encoder
+ * output, rows >= seq_len are zero (wan_wrapper.py:52-53).  One prompt per call. */
+int rtv_t5_encode(const rtv_t5_config* cfg, const rtv_t5_weights* w, const int* ids, int seq_len, int out_rows,
+                  void* workspace, size_t workspace_bytes, void* out, rtv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
