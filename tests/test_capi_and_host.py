@@ -156,3 +156,44 @@ def test_resample_array_matches_reference_rule():
     assert resample_array([1, 2, 3], 3) == [1, 2, 3]
     assert resample_array(list(range(24)), 12) == [0, 2, 4, 6, 8, 10, 13, 15, 17, 19, 21, 23]
     assert resample_array(list(range(5)), 9) == [0, 0, 1, 2, 2, 2, 3, 4, 4]
+
+
+def test_text_encoder_host_logic_matches_oracle():
+    """The product's bias-table bucket rule (text_encoder.relative_position_bucket) against the oracle's restatement of
+    t5.py:238-265 over every distance of a 512-token window; prompt cleaning; CPU refusal."""
+    import pytest
+    from oracle import t5_oracle as to
+    from realtime_video_amd.text_encoder import WanTextEncoder, relative_position_bucket, whitespace_clean
+    rel = torch.arange(-511, 512)
+    assert torch.equal(relative_position_bucket(rel), to.relative_position_bucket(rel))
+    assert int(relative_position_bucket(rel).max()) == 31 and int(relative_position_bucket(rel).min()) == 0
+    assert whitespace_clean("  a &amp;amp; b \n\t c ") == "a & b c"
+    enc = WanTextEncoder(device="cpu", text_len=48, **to.TINY_T5)
+    with pytest.raises(RuntimeError):
+        enc.encode_ids(torch.zeros(1, 4, dtype=torch.long), torch.ones(1, 4, dtype=torch.long))   # weights not loaded
+
+
+def test_context_parallel_exchange_choice_and_cache_heads():
+    """"auto" picks the all-to-all head exchange whenever the head count divides; the KV cache of a real rank then holds
+    num_heads / world heads (a single-process simulation shares one full-head cache)."""
+    import pytest
+    from realtime_video_amd.causal_model import CausalWanModel
+    from realtime_video_amd.parallel import SimulatedContextParallel
+    cp = SimulatedContextParallel(8)
+    assert cp.head_exchange(40) and not cp.head_exchange(12)
+    assert not SimulatedContextParallel(8, "rows").head_exchange(40)
+    assert not SimulatedContextParallel(1).head_exchange(40)
+    with pytest.raises(ValueError):
+        SimulatedContextParallel(8, "heads").head_exchange(12)
+    m = CausalWanModel(dim=1024, ffn_dim=2048, num_heads=8, num_layers=1, device="cpu")
+    assert m.kv_cache_heads() == 8
+    m.context_parallel = cp
+    assert m.kv_cache_heads() == 8                     # simulation: all ranks in one process, one shared cache
+
+    class OneRank(SimulatedContextParallel):
+        def local_ranks(self):
+            return [3]
+    m.context_parallel = OneRank(8)
+    assert m.kv_cache_heads() == 1
+    m.context_parallel = OneRank(8, "rows")
+    assert m.kv_cache_heads() == 8
