@@ -176,6 +176,28 @@ def main():
         model.context_parallel = SimulatedContextParallel(args.simulate_cp, args.cp_exchange)
         args.no_vae = True
     wr = WanDiffusionWrapper(model, timestep_shift=5.0)
+
+    class TimedTransformer:
+        """hipEvents around every WanDiffusionWrapper.forward on the launch stream: BASELINE.json's "per-step DiT latency"
+        (denoise steps) and the KV-recompute forward, collectives included under context parallelism."""
+
+        def __init__(self, inner):
+            self.inner, self.events, self.on = inner, [], False
+
+        def __getattr__(self, name):
+            return getattr(self.inner, name)
+
+        def __call__(self, *a, **k):
+            if not self.on:
+                return self.inner(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.inner(*a, **k)
+            e1.record()
+            self.events.append((model.block_mask is not None, e0, e1))
+            return out
+
+    wr = TimedTransformer(wr)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]), dev,
                                    generator=wr)
     if args.no_vae:
@@ -223,6 +245,7 @@ def main():
     ops.prof_reset()
     ops.prof_enable(args.profile_classes != "none",
                     None if args.profile_classes == "all" else [c for c in args.profile_classes.split(",") if c != "none"])
+    wr.on = True
     t0 = time.perf_counter()
     frames = 0
     for _ in range(args.steps):
@@ -239,6 +262,8 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(out.float()).all(), "non-finite output"
 
+    step_ms = [e0.elapsed_time(e1) for rc, e0, e1 in wr.events if not rc]
+    recompute_ms = [e0.elapsed_time(e1) for rc, e0, e1 in wr.events if rc]
     prof = {k: ops.prof_read(k) for k in ("gemm", "attn", "layernorm", "rope", "conv", "misc")}
     if rank != 0:
         return
@@ -280,6 +305,8 @@ def main():
                 + "; VAE decode "
                 f"sharded by output rows ({world} stripes + conv halos, one pixel all-gather per block), first-frame "
                 f"re-encode replicated" if use_cp else f"{world} independent replicas"),
+            "dit_ms_per_denoise_step": sum(step_ms) / max(1, len(step_ms)),        # BASELINE.json "per-step DiT latency"
+            "dit_ms_per_recompute_forward": sum(recompute_ms) / max(1, len(recompute_ms)) if recompute_ms else None,
             # kernel-class times exist only for the classes bracketed with events (--profile-classes; 'all' = diagnostic)
             "dit_ms_per_forward": ((prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
                                     + prof["misc"]["ms"]) / (args.steps * fwd_per_block)
