@@ -11,7 +11,7 @@ from realtime_video_amd import ops  # noqa: E402
 cfgs = [int(c) for c in sys.argv[1:]] or [0, 1, 50, 4]
 ops.ensure_gemm_workspace(torch.device("cuda"))
 shapes = [("qkv", 15360, 5120), ("o/cq/co", 5120, 5120), ("ffn0", 13824, 5120), ("ffn2", 5120, 13824)]
-for m in (4680, 2340, 1170, 585):
+for m in [int(x) for x in os.environ.get("CP_M", "4680,2340,1170,585").split(",")]:
     for name, n, k in shapes:
         a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
         w = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
