@@ -542,3 +542,43 @@ def test_hip_graph_replay_equals_eager():
             assert sum(isinstance(v, dict) for v in model._graphs.values()) >= 2    # recompute + denoise step captured
     for a, b in zip(outs[False], outs[True]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("exchange,tile_cfg", [("heads", 4), ("rows", 4), ("heads", 0)])
+def test_full_width_layer_context_parallel_equals_unsharded(exchange, tile_cfg):
+    """BASELINE config 4 at full width: ONE layer of the 14B architecture (d 5120, 40 heads, ffn 13824), 4680 tokens, cache of
+    9360 rows - the 8-way token-sharded forward (585 rows per rank, 5 heads per rank under the head exchange) against the
+    unsharded one, recompute pass and denoise step at cache offset 4680.  Size-independent property at the production
+    shapes (tile edges at 585 rows, 128-row attention workgroups).  With a shape-independent K summation order (tile
+    config 4: the ping-pong GEMM without split-K) the two are bit-identical; the default config splits K where a launch
+    leaves CUs idle - which tiles that hits depends on the row count - so there the fp32 partial sums associate
+    differently and the outputs agree to bf16 rounding (rel-L2 <= 8e-3: one-ulp flips, 2^-8 relative, carried through the layer)."""
+    from realtime_video_amd.causal_model import CausalWanModel
+    from realtime_video_amd.parallel import SimulatedContextParallel
+    from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
+    cfg = dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1)
+    g = torch.Generator().manual_seed(3)
+    lat = [torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16).to(DEV) for _ in range(2)]
+    ctx = torch.zeros(512, 4096, dtype=torch.bfloat16)
+    ctx[:64] = torch.randn(64, 4096, generator=g).to(torch.bfloat16)
+    cond = {"prompt_embeds": [ctx.to(DEV)]}
+    outs = []
+    for cp in (None, SimulatedContextParallel(8, exchange)):
+        model = CausalWanModel(text_dim=4096, freq_dim=256, device=DEV, **cfg).init_random_weights(seed=0)
+        model.context_parallel = cp
+        model.gemm_tile_cfg = tile_cfg
+        wr = WanDiffusionWrapper(model, timestep_shift=5.0)
+        kv, ca = _caches(cfg, 9360)
+        model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560,
+                                                                     num_frame_per_block=3)
+        f_rc, _ = wr(lat[0], cond, torch.zeros([1, 3], dtype=torch.int64, device=DEV), kv, ca, current_start=4680)
+        model.block_mask = None
+        f_dn, _ = wr(lat[1], cond, torch.ones([1, 3], dtype=torch.int64, device=DEV) * 700, kv, ca, current_start=4680)
+        assert torch.isfinite(f_dn.float()).all() and float(f_dn.float().abs().mean()) > 0
+        outs.append((f_rc.clone(), f_dn.clone(), kv[0]["k"].clone(), kv[0]["v"].clone()))
+        del model, wr
+    for a, b in zip(outs[0], outs[1]):
+        if tile_cfg == 4:
+            assert torch.equal(a, b)
+        else:
+            assert rel_l2(a, b) <= 8e-3

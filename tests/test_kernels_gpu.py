@@ -387,3 +387,45 @@ def test_gemm_fp8_fused_epilogue(ops):
     assert rel_l2(out, ref) <= 4e-3
     out = ops.gemm_fp8(aq, sa, wq, float(sw), bias=b, act=1)
     assert rel_l2(out, torch.nn.functional.gelu(yb, approximate="tanh")) <= 4e-3
+
+
+# ----------------------------------------------------------------------------------------- BASELINE config 3 sizes
+@pytest.mark.parametrize("name,N,K,act", [("qkv", 15360, 5120, 0), ("o", 5120, 5120, 0), ("ffn0", 13824, 5120, 1),
+                                          ("ffn2", 5120, 13824, 0)])
+def test_gemm_full_14b_shapes(ops, name, N, K, act):
+    """The four projection shapes of the 14B layer at the full token count (M = 4680) against the fp32 eager chain, default
+    tile config with split-K workspace attached (the bench's configuration)."""
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    a, w, b = _randn(4680, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+    out = ops.gemm(a, w, bias=b, act=act)
+    ref = _gemm_ref(a, w, b, act, None, 0, None)
+    assert rel_l2(out, ref) <= 4e-3
+    assert max_abs(out, ref) <= 0.05 * float(ref.float().abs().max()) + 1e-3
+    # linearity in the activations (size-independent property): (2a) W^T + b - (a W^T + b) == a W^T up to bf16 rounding
+    if act == 0:
+        out2 = ops.gemm((a.float() * 2).to(a.dtype), w, bias=b)
+        lin = (out2.float() - out.float())
+        assert rel_l2(lin, (ref.float() - b.float())) <= 1e-2
+
+
+def test_attention_full_size_properties(ops):
+    """Self-attention at the benchmarked size (4680 queries x 9360 cached keys x 40 heads, the 14B denoise step): (1) against
+    the fp32 definition on a sample of heads; (2) invariance under a permutation of the keys (softmax-weighted sums do not
+    depend on key order; the online softmax then meets the tile maxima in another order, so this exercises the rescale
+    path); (3) duplicating every key/value pair leaves the output unchanged."""
+    H, Lq, Lkv = 40, 4680, 9360
+    q = _randn(1, Lq, H, 128, seed=1)
+    k = _randn(1, Lkv, H, 128, seed=2)
+    v = _randn(1, Lkv, H, 128, seed=3)
+    out = ops.attn_fwd(q, k, v)
+    for h in (0, 17, 39):
+        ref = _attn_ref(q[:, :, h:h + 1], k[:, :, h:h + 1], v[:, :, h:h + 1])
+        assert max_abs(out[:, :, h:h + 1], ref) <= 2e-2
+    perm = torch.randperm(Lkv, generator=torch.Generator().manual_seed(4)).to(DEV)
+    out_p = ops.attn_fwd(q, k[:, perm].contiguous(), v[:, perm].contiguous())
+    assert rel_l2(out_p, out) <= 5e-3
+    hs = slice(0, 8)                                            # duplication on 8 heads (memory)
+    k2 = torch.cat([k[:, :, hs], k[:, :, hs]], 1).contiguous()
+    v2 = torch.cat([v[:, :, hs], v[:, :, hs]], 1).contiguous()
+    out_d = ops.attn_fwd(q[:, :, hs].contiguous(), k2, v2)
+    assert rel_l2(out_d, out[:, :, hs]) <= 5e-3
