@@ -302,3 +302,45 @@ def test_frame_downloader_matches_reference_callback():
     assert dl.frame_ids(tickets[-1]) == ["id2"]
     with pytest.raises(KeyError):
         dl.fetch(tickets[0])                                  # slot already reused
+
+
+# ----------------------------------------------------------------------------------------- BASELINE sizes (480 x 832)
+def test_conv3d_full_resolution_layer():
+    """The decoder's dominant layer at its production size: causal 3x3x3 conv 96 -> 96 on 4 frames of 480 x 832 (two cached
+    time slices in front) + bias + residual, against torch's fp32 conv3d on the GPU."""
+    T, H, W, C = 4, 480, 832, 96
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(T + 2, H, W, C, generator=g) * 0.5).half().to(DEV)
+    w = (torch.randn(C, C, 3, 3, 3, generator=g) * (27 * C) ** -0.5).half().to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).half().to(DEV)
+    res = torch.randn(T, H, W, C, generator=g).half().to(DEV)
+    out = _conv_cl(x, w, b, T, H, W, 3, 3, 3, residual=res)
+    xin = x.permute(3, 0, 1, 2).unsqueeze(0).float()
+    ref = F.conv3d(F.pad(xin, (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+    ref = ref.half().float() + res.float()
+    assert max_abs(out, ref) <= 1e-2 and rel_l2(out, ref) <= 2e-3
+
+
+def test_full_size_decode_row_sharded_equals_unsharded():
+    """Streaming decode at the benchmarked size (latents 60 x 104 -> 480 x 832): first block (3 latent frames -> 9 pixel
+    frames) and a streamed second block (12 frames); the 8 row stripes of the sharded decode (BASELINE config 4) are
+    bit-identical to the rows of the unsharded one, pixels stay finite and inside [-1, 1]."""
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    full = VAEDecoderWrapper(DEV).init_random_weights(seed=1)
+    g = torch.Generator().manual_seed(9)
+    zs = [torch.randn(1, 3, 16, 60, 104, generator=g).half().to(DEV) for _ in range(2)]
+    refs, cache = [], [None] * 55
+    for z in zs:
+        px, cache = full(z, *cache)
+        assert torch.isfinite(px).all() and float(px.abs().max()) <= 1.0
+        refs.append(px)
+    assert refs[0].shape == (1, 9, 3, 480, 832) and refs[1].shape == (1, 12, 3, 480, 832)
+    del full, cache
+    for r in (0, 3, 7):                                                     # first, interior and last stripe
+        shard = VAEDecoderWrapper(DEV, row_shard=(r, 8)).init_random_weights(seed=1)
+        r0, r1 = shard.row_range(60)
+        c = [None] * 55
+        for z, ref in zip(zs, refs):
+            px, c = shard(z, *c)
+            assert torch.equal(px, ref[:, :, :, r0:r1])
+        del shard, c
