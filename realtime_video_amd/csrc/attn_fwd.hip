@@ -65,6 +65,9 @@ __device__ __forceinline__ u32x2 lds_tr_read(const char* p) {
   return __builtin_bit_cast(u32x2, t);
 }
 
+// Occupancy: ~220 unified registers -> 2 waves per SIMD (the second __launch_bounds__ argument), i.e. ONE 8-wave workgroup or
+// two 4-wave workgroups per CU.  A 6-wave build cannot help partial rounds: its workgroup would still occupy a CU for the
+// time its two doubly-loaded SIMDs need.
 template <bool F16, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
   constexpr int ATT_QT = ATT_QW * NW;                    // query rows per workgroup (256 / 128)
