@@ -212,6 +212,54 @@ def golden_vae_encoder(ref):
     print("vae_encoder.pt", [tuple(m.shape) for m in out["mu"]], sum(c is not None for c in cache), "cache slots")
 
 
+def golden_session():
+    """The reference's own GenerationSession (release_server.py:344-736) driven for 3 blocks on the CPU: tiny DiT through the
+    reference's CausalWanModel / WanDiffusionWrapper / CausalInferencePipeline, c = 3, 4 steps, keep_first_frame = False (block 2
+    takes the first-frame re-encode branch, :572-575), stand-in VAE / text encoder (oracle/standins.py).  Pins the session
+    orchestration of oracle.wan_oracle.SessionOracle and of the native session mirror."""
+    import types
+    from oracle import standins
+    rs, CIP = ref_shim.load_release_server()
+    ref = ref_shim.load()
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    # `.config` is diffusers' register_to_config sugar (stubbed away by the shim); the pipeline reads two fields of it
+    model.config = types.SimpleNamespace(num_heads=cfg["num_heads"], dim=cfg["dim"])
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.zeros(1, 512, TEXT_DIM, dtype=torch.bfloat16)
+    prompt[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=False, num_frame_per_block=3,
+                                 independent_first_frame=False)
+    pipe = CIP(args, "cpu", generator=wr, text_encoder=standins.StandinTextEncoder(prompt), vae=object())
+    enc_calls = []
+
+    def encoder(frames, cache, stream=False):
+        enc_calls.append(frames.float().clone())
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = rs.Models(standins.StandinTextEncoder(prompt), wr, pipe, encoder, standins.standin_decoder)
+    params = rs.GenerateParams(prompt="synthetic", seed=9, num_blocks=3, num_denoising_steps=4, kv_cache_num_frames=3,
+                               keep_first_frame=False)
+    sess = rs.GenerationSession(params, types.SimpleNamespace(use_taehv=False), frame_callback=lambda *a, **k: None, models=models)
+    out = {"noise": sess.noise.clone(), "steps": sess.denoising_step_list.clone(), "prompt": prompt, "blocks": [], "indices": [],
+           "pixels_shape": [], "pixel_sample": []}
+    for b in range(3):
+        px = sess.generate_block_internal(models)
+        out["blocks"].append(sess.last_pred.clone())
+        out["indices"].append((int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                               sess.current_start_frame, sess.block_idx, sess.total_frames_sent))
+        out["pixels_shape"].append(tuple(px.shape))
+        out["pixel_sample"].append(px[0, :, :, ::40, ::52].clone())
+    out["all_latents"] = sess.all_latents.clone()
+    out["encoder_inputs"] = [f[..., ::40, ::52].clone() for f in enc_calls]
+    out["encoder_input_shapes"] = [tuple(f.shape) for f in enc_calls]
+    out["kv_shape"] = tuple(pipe.kv_cache1[0]["k"].shape)
+    torch.save(out, os.path.join(OUT, "session_reference.pt"))
+    print("session_reference.pt", out["indices"], out["pixels_shape"], out["encoder_input_shapes"])
+
+
 def golden_t5():
     """Text encoder: the reference's own T5Encoder (wan/modules/t5.py:267-313, shared_pos=False like umt5_xxl,
     float32 like WanTextEncoder) at tiny dims with head_dim 64, two prompts of 29 and 48 tokens in a 48-slot window, plus
@@ -242,7 +290,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5", "session"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -255,3 +303,5 @@ if __name__ == "__main__":
         golden_vae_encoder(ref)
     if "t5" in which:
         golden_t5()
+    if "session" in which:      # last: load_release_server() patches torch.cuda for the rest of the process
+        golden_session()

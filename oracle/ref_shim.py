@@ -148,3 +148,62 @@ def load_t5():
     finally:
         torch.cuda.current_device = real
     return mod
+
+
+class _NoCudaObject:
+    """Stand-in for torch.cuda.Stream / torch.cuda.Event while the reference's serving module runs on the CPU."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, *a, **k):
+        pass
+
+    def wait_event(self, *a, **k):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+def load_release_server():
+    """The reference's release_server.py (GenerationSession, GenerateParams, Models) and its CausalInferencePipeline,
+    imported on the CPU: module-level CUDA calls (release_server.py:88-90, demo_utils/memory.py:9) are patched so that `gpu`
+    is the CPU, third-party modules that are absent and unused on this path (omegaconf, torchvision, cv2, requests) are
+    stubbed, `pipeline/__init__.py` (which imports the training pipelines) is bypassed.  The patches stay in place: this
+    is a one-way switch for golden-minting processes only.  Returns (release_server module, CausalInferencePipeline)."""
+    load()
+    if "release_server" in sys.modules:
+        return sys.modules["release_server"], sys.modules["pipeline.causal_inference"].CausalInferencePipeline
+    for n in ("omegaconf", "torchvision", "torchvision.transforms", "torchvision.transforms.functional", "cv2", "requests"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["omegaconf"].OmegaConf = type("OmegaConf", (), {})
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    # the HTTP / WebSocket layer below the session class is control plane: its decorators become no-ops
+    class _App:
+        def __init__(self, *a, **k):
+            self.state = types.SimpleNamespace()
+
+        def __getattr__(self, name):
+            return lambda *a, **k: (lambda f: f)
+
+    fa = types.ModuleType("fastapi")
+    fa.FastAPI = _App
+    fa.File = lambda *a, **k: None
+    for n in ("WebSocket", "WebSocketDisconnect", "UploadFile"):
+        setattr(fa, n, type(n, (Exception,), {}))
+    fam, fac, far = (types.ModuleType(n) for n in ("fastapi.middleware", "fastapi.middleware.cors", "fastapi.responses"))
+    fac.CORSMiddleware = object
+    far.HTMLResponse = far.JSONResponse = object
+    sys.modules.update({"fastapi": fa, "fastapi.middleware": fam, "fastapi.middleware.cors": fac, "fastapi.responses": far})
+    torch.cuda.current_device = lambda: 0
+    import demo_utils.memory  # noqa: F401   (gpu = device(f"cuda:{current_device()}") at import)
+    _pkg("pipeline", REF + "/pipeline")
+    import pipeline.causal_inference as ci
+    torch.cuda.current_device = lambda: torch.device("cpu")
+    torch.cuda.Stream = _NoCudaObject
+    torch.cuda.Event = _NoCudaObject
+    torch.Tensor.cuda = lambda self, *a, **k: self          # v2v.encode_video_latent calls frames.cuda()
+    import release_server as rs
+    return rs, ci.CausalInferencePipeline

@@ -582,3 +582,49 @@ def test_full_width_layer_context_parallel_equals_unsharded(exchange, tile_cfg):
             assert torch.equal(a, b)
         else:
             assert rel_l2(a, b) <= 8e-3
+
+
+def test_native_session_matches_reference_generation_session(golden):
+    """The native GenerationSession mirror (HIP DiT forward, native cache manager) against the golden minted by running the
+    reference's OWN GenerationSession for 3 blocks (oracle/make_golden.py `session`; stand-in VAE / text encoder of
+    oracle/standins.py on both sides): latents per block, cache indices, frame accounting (block 0 sends 6 of its 9
+    frames), and the pixel frame handed to the encoder by the first-frame re-encode branch of block 2."""
+    from oracle import standins
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models
+    gold = golden("session_reference.pt")
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
+                                   DEV, generator=wr, text_encoder=None, vae=None)
+    enc_inputs = []
+
+    def encoder(frames, cache, stream=False):
+        enc_inputs.append(frames.float().cpu())
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=standins.StandinTextEncoder(gold["prompt"].to(DEV)),
+                    vae_decoder=standins.standin_decoder, vae_encoder=encoder)
+    sent = []
+    sess = GenerationSession(GenerateParams(seed=9, num_blocks=3, num_denoising_steps=4, kv_cache_num_frames=3,
+                                            keep_first_frame=False), models,
+                             frame_callback=lambda px, ids, ev: sent.append(tuple(px.shape)), device=DEV)
+    cpu_rnd = torch.Generator().manual_seed(9)          # the reference draws the latent noise, then the re-noising, from ONE generator
+    noise = torch.randn([1, 9, 16, 60, 104], dtype=torch.bfloat16, generator=cpu_rnd)
+    assert torch.equal(noise, gold["noise"])
+    sess.noise = noise.to(DEV)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    assert torch.equal(sess.denoising_step_list.cpu(), gold["steps"])
+    for b in range(3):
+        px = sess.generate_block()
+        assert rel_l2(sess.last_pred.cpu(), gold["blocks"][b]) <= 5e-2, b
+        assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                sess.current_start_frame, sess.block_idx, sess.total_frames_sent) == gold["indices"][b]
+        assert tuple(px.shape) == gold["pixels_shape"][b] == sent[b]
+        assert max_abs(px[0, :, :, ::40, ::52].cpu(), gold["pixel_sample"][b]) <= 0.1
+    assert rel_l2(sess.all_latents.cpu(), gold["all_latents"]) <= 5e-2
+    assert tuple(pipe.kv_cache1[0]["k"].shape) == gold["kv_shape"]
+    assert [tuple(f.shape) for f in enc_inputs] == gold["encoder_input_shapes"]
+    assert max_abs(enc_inputs[0][..., ::40, ::52], gold["encoder_inputs"][0]) <= 0.1

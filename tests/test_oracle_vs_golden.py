@@ -193,3 +193,51 @@ def test_t5_relative_position_buckets_known_values():
     from oracle import t5_oracle as to
     rel = torch.tensor([0, 1, 7, 8, 11, 12, 15, 16, 64, 127, 128, 500, -1, -7, -8, -127, -128, -511])
     assert to.relative_position_bucket(rel).tolist() == [0, 17, 23, 24, 24, 25, 25, 26, 30, 31, 31, 31, 1, 7, 8, 15, 15, 15]
+
+
+def _session_harness_first_frame(frames_cache):
+    """release_server.py:572-575 + v2v.py:138-158 with the stand-in encoder: the oldest cached pixel frame, as fp16, through
+    the (size-preserving) bicubic resize, into the encoder; returns [1, 1, 16, h, w]."""
+    from oracle import standins
+    frames = frames_cache[0][0].half()                                               # [1, 3, H, W]
+    frames = torch.nn.functional.interpolate(frames, size=(480, 832), mode="bicubic").transpose(0, 1).to(torch.float16)
+    mu, _ = standins.standin_encoder(frames.unsqueeze(0), [None] * 55, stream=False)
+    return mu.squeeze(0).to(torch.float16).transpose(0, 1)[None], frames
+
+
+def test_session_oracle_matches_reference_generation_session(golden):
+    """SessionOracle (restatement of GenerationSession.recompute_kv_cache / generate_block_internal) against a golden minted
+    by running the reference's OWN GenerationSession class for 3 blocks on the CPU (oracle/make_golden.py `session`): same
+    noise stream (one CPU generator: the latent noise first, then the re-noising draws), same schedule, same context-frame
+    selection incl. the first-frame re-encode branch at block 2, same cache bookkeeping."""
+    from collections import deque
+    from oracle import standins
+    gold = golden("session_reference.pt")
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    rnd = torch.Generator().manual_seed(9)
+    noise = torch.randn([1, 9, 16, 60, 104], dtype=torch.bfloat16, generator=rnd)
+    assert torch.equal(noise, gold["noise"])
+    frames_cache, enc_inputs = deque(maxlen=9), []
+
+    def first_frame(block_idx):
+        lat, frames = _session_harness_first_frame(frames_cache)
+        enc_inputs.append(frames)
+        return lat
+
+    ora = wo.SessionOracle(w, cfg, [gold["prompt"][0]], noise, kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=0,
+                           first_frame_fn=first_frame)
+    ora.rnd = rnd                                                                    # continues after the noise draw
+    assert torch.equal(ora.denoising_step_list, gold["steps"])
+    vae_cache = [None] * 55
+    for b in range(3):
+        out = ora.generate_block()
+        assert rel_l2(out, gold["blocks"][b]) <= 1e-2, b
+        px, vae_cache = standins.standin_decoder(out.half(), *vae_cache)
+        frames_cache.extend(px.split(1, dim=1))
+        assert (int(ora.kv_cache[0]["global_end_index"]), int(ora.kv_cache[0]["local_end_index"]),
+                ora.current_start_frame, ora.block_idx) == gold["indices"][b][:4]
+    assert rel_l2(ora.all_latents, gold["all_latents"]) <= 1e-2
+    assert len(enc_inputs) == len(gold["encoder_inputs"]) == 1                        # only block 2 re-encodes
+    assert tuple(enc_inputs[0].unsqueeze(0).shape) == gold["encoder_input_shapes"][0]
+    assert max_abs(enc_inputs[0].unsqueeze(0).float()[..., ::40, ::52], gold["encoder_inputs"][0]) <= 2e-2
