@@ -260,6 +260,77 @@ def golden_session():
     print("session_reference.pt", out["indices"], out["pixels_shape"], out["encoder_input_shapes"])
 
 
+def webcam_frames(seed=31, counts=(11, 12, 14)):
+    """Input frames of the webcam golden: per block a list of [3, 480, 832] fp16 frames in [-1, 1] (smooth in space so that
+    the stand-in encoder's pooling is well conditioned)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for n in counts:
+        low = torch.rand(n, 3, 15, 26, generator=g) * 2 - 1
+        out.append(list(torch.nn.functional.interpolate(low, size=(480, 832), mode="bilinear").half()))
+    return out
+
+
+def golden_session_webcam():
+    """The reference's GenerationSession in webcam (streaming v2v) mode with a prompt transition (release_server.py:489-527,
+    :402-413, :651-666): 3 blocks, strength 0.8, frames put on the session's frame_queue as tensors (the JPEG decoding of
+    push_frame is control plane), 11 / 12 / 14 frames waiting at blocks 0 / 1 / 2 (resampled to 9 / 12 / 12), prompt
+    interpolation over 2 steps requested after block 0.  torch.randn_like of the input-noising uses the global generator:
+    it is seeded with 100 + block before every block."""
+    import types
+    from oracle import standins
+    rs, CIP = ref_shim.load_release_server()
+    ref = ref_shim.load()
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):       # generate_block_internal moves the encoded input with .to("cuda") (:656)
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return orig_to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    model.config = types.SimpleNamespace(num_heads=cfg["num_heads"], dim=cfg["dim"])
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    g = torch.Generator().manual_seed(5)
+    prompts = []
+    for _ in range(2):
+        p = torch.zeros(1, 512, TEXT_DIM, dtype=torch.bfloat16)
+        p[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+        prompts.append(p)
+    text = standins.StandinTextEncoder(prompts[0], {"second prompt": prompts[1]})
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=False, num_frame_per_block=3,
+                                 independent_first_frame=False)
+    pipe = CIP(args, "cpu", generator=wr, text_encoder=text, vae=object())
+    enc_calls = []
+
+    def encoder(frames, cache, stream=False):
+        enc_calls.append((tuple(frames.shape), bool(stream), frames.float()[..., ::40, ::52].clone()))
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = rs.Models(text, wr, pipe, encoder, standins.standin_decoder)
+    params = rs.GenerateParams(prompt="first prompt", seed=9, num_blocks=3, num_denoising_steps=4, kv_cache_num_frames=3,
+                               keep_first_frame=False, webcam_mode=True, strength=0.8)
+    sess = rs.GenerationSession(params, types.SimpleNamespace(use_taehv=False), frame_callback=lambda *a, **k: None, models=models)
+    out = {"steps": sess.denoising_step_list.clone(), "prompts": prompts, "blocks": [], "indices": [], "prompt_used": []}
+    for b, frames in enumerate(webcam_frames()):
+        for f in frames:
+            sess.frame_queue.put(f)
+        torch.manual_seed(100 + b)
+        sess.generate_block_internal(models)
+        out["blocks"].append(sess.last_pred.clone())
+        out["prompt_used"].append(sess.current_prompt_embeds.clone())
+        out["indices"].append((int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                               sess.current_start_frame, sess.block_idx, sess.total_frames_sent))
+        if b == 0:
+            sess.interpolate_prompt_embeds(models, "second prompt", 2)
+    out["all_latents"] = sess.all_latents.clone()
+    out["encoder_calls"] = enc_calls
+    torch.Tensor.to = orig_to
+    torch.save(out, os.path.join(OUT, "session_webcam_reference.pt"))
+    print("session_webcam_reference.pt", out["indices"], [(c[0], c[1]) for c in enc_calls], out["steps"])
+
+
 def golden_t5():
     """Text encoder: the reference's own T5Encoder (wan/modules/t5.py:267-313, shared_pos=False like umt5_xxl,
     float32 like WanTextEncoder) at tiny dims with head_dim 64, two prompts of 29 and 48 tokens in a 48-slot window, plus
@@ -290,7 +361,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5", "session"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5", "session", "webcam"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -303,5 +374,7 @@ if __name__ == "__main__":
         golden_vae_encoder(ref)
     if "t5" in which:
         golden_t5()
-    if "session" in which:      # last: load_release_server() patches torch.cuda for the rest of the process
+    if "session" in which:      # from here on load_release_server() has patched torch.cuda for the rest of the process
         golden_session()
+    if "webcam" in which:
+        golden_session_webcam()

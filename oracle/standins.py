@@ -26,20 +26,35 @@ def standin_decoder(latents, *cache):
 
 
 def standin_encoder(frames, cache, stream=False):
-    """Contract of VAEEncoderWrapper.forward (vae_block3.py:122-175) for single frames: frames [1, 3, 1, H, W] half ->
-    (mu [1, 16, 1, H/8, W/8], cache)."""
-    x = frames.float()[0, :, 0]                                                    # [3, H, W]
-    pooled = torch.nn.functional.avg_pool2d(x.unsqueeze(0), 8)[0]                   # [3, h, w]
+    """Contract of VAEEncoderWrapper.forward (vae_block3.py:122-175): frames [1, 3, T, H, W] half -> (mu [1, 16, T', H/8, W/8],
+    cache).  Fresh / non-streamed calls take 1 + 4k frames (first frame alone, then groups of 4), streamed calls 4k frames."""
+    x = frames.float()[0]                                                          # [3, T, H, W]
+    T = x.shape[1]
+    if stream:
+        assert T % 4 == 0, T
+        groups = [range(4 * i, 4 * i + 4) for i in range(T // 4)]
+    else:
+        assert (T - 1) % 4 == 0, T
+        groups = [range(0, 1)] + [range(1 + 4 * i, 5 + 4 * i) for i in range((T - 1) // 4)]
     scale = 1.0 + 0.1 * torch.arange(16, device=x.device, dtype=x.dtype).view(16, 1, 1)
-    z = pooled[torch.arange(16, device=x.device) % 3] * scale                      # [16, h, w]
-    return z.view(1, 16, 1, *z.shape[1:]), cache
+    idx = torch.arange(16, device=x.device) % 3
+    out = []
+    for g in groups:
+        m = x[:, list(g)].mean(dim=1)                                              # [3, H, W]
+        pooled = torch.nn.functional.avg_pool2d(m.unsqueeze(0), 8)[0]               # [3, h, w]
+        out.append(pooled[idx] * scale)
+    z = torch.stack(out, dim=1)                                                    # [16, T', h, w]
+    return z.unsqueeze(0), cache
 
 
 class StandinTextEncoder:
-    """WanTextEncoder's call contract (utils/wan_wrapper.py:43-56) returning fixed embeddings."""
+    """WanTextEncoder's call contract (utils/wan_wrapper.py:43-56) returning fixed embeddings; `by_prompt` maps specific
+    prompt strings to other embeddings (prompt transitions)."""
 
-    def __init__(self, prompt_embeds):
+    def __init__(self, prompt_embeds, by_prompt=None):
         self.prompt_embeds = prompt_embeds
+        self.by_prompt = by_prompt or {}
 
     def __call__(self, text_prompts=None):
-        return {"prompt_embeds": self.prompt_embeds.clone()}
+        e = self.by_prompt.get(text_prompts[0] if text_prompts else None, self.prompt_embeds)
+        return {"prompt_embeds": e.clone()}

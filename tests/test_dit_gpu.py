@@ -628,3 +628,59 @@ def test_native_session_matches_reference_generation_session(golden):
     assert tuple(pipe.kv_cache1[0]["k"].shape) == gold["kv_shape"]
     assert [tuple(f.shape) for f in enc_inputs] == gold["encoder_input_shapes"]
     assert max_abs(enc_inputs[0][..., ::40, ::52], gold["encoder_inputs"][0]) <= 0.1
+
+
+def test_native_webcam_session_matches_reference_generation_session(golden):
+    """Streaming video-to-video + prompt transition against the golden minted by the reference's own GenerationSession in
+    webcam mode (oracle/make_golden.py `webcam`: 3 blocks, strength 0.8, 11 / 12 / 14 queued frames resampled to 9 / 12 / 12,
+    prompt interpolation over 2 steps requested after block 0, first-frame re-encode at block 2; stand-in VAE / text
+    encoder on both sides).  Checked: latents per block, the schedule, cache indices and frame accounting, the sequence of
+    encoder calls (shapes, stream flags, sampled input pixels) and the prompt embedding every block used."""
+    from oracle import standins
+    from oracle import wan_oracle as wo
+    from oracle.make_golden import webcam_frames
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models
+    gold = golden("session_webcam_reference.pt")
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
+                                   DEV, generator=wr, text_encoder=None, vae=None)
+    calls = []
+
+    def encoder(frames, cache, stream=False):
+        calls.append((tuple(frames.shape), bool(stream), frames.float()[..., ::40, ::52].cpu()))
+        return standins.standin_encoder(frames, cache, stream)
+
+    prompts = [p.to(DEV) for p in gold["prompts"]]
+    text = standins.StandinTextEncoder(prompts[0], {"second prompt": prompts[1]})
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=text, vae_decoder=standins.standin_decoder, vae_encoder=encoder)
+    sess = GenerationSession(GenerateParams(prompt="first prompt", seed=9, num_blocks=3, num_denoising_steps=4,
+                                            kv_cache_num_frames=3, keep_first_frame=False, webcam_mode=True, strength=0.8),
+                             models, device=DEV)
+    assert torch.allclose(sess.denoising_step_list.cpu().float(), gold["steps"].float())
+    cpu_rnd = torch.Generator().manual_seed(9)
+    torch.randn([1, 9, 16, 60, 104], dtype=torch.bfloat16, generator=cpu_rnd)      # the session's (unused) latent noise comes first
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    for b, frames in enumerate(webcam_frames()):
+        for f in frames:
+            sess.push_frame(f.to(DEV))
+        # the reference noises the input with torch.randn_like on the GLOBAL CPU generator (seeded 100 + b by the golden
+        # script); its argument is the movedim(1, 2) view of the [1, 16, 3, h, w] encoder output, and normal_ on such a
+        # non-contiguous tensor takes torch's element-wise path - so the draw is reproduced by the very same call
+        def like(t, b=b):
+            torch.manual_seed(100 + b)
+            return torch.randn_like(torch.empty([1, 16, 3, 60, 104], dtype=torch.bfloat16).movedim(1, 2)).to(t.device)
+        sess._randn_like = like
+        sess.generate_block()
+        assert rel_l2(sess.last_pred.cpu(), gold["blocks"][b]) <= 5e-2, b
+        assert torch.equal(sess.current_prompt_embeds.cpu(), gold["prompt_used"][b])
+        assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                sess.current_start_frame, sess.block_idx, sess.total_frames_sent) == gold["indices"][b]
+        if b == 0:
+            sess.interpolate_prompt_embeds(models, "second prompt", 2)
+    assert rel_l2(sess.all_latents.cpu(), gold["all_latents"]) <= 5e-2
+    assert [(c[0], c[1]) for c in calls] == [(c[0], c[1]) for c in gold["encoder_calls"]]
+    for ours, ref in zip(calls, gold["encoder_calls"]):
+        assert max_abs(ours[2], ref[2]) <= 0.1
