@@ -331,6 +331,47 @@ def golden_session_webcam():
     print("session_webcam_reference.pt", out["indices"], [(c[0], c[1]) for c in enc_calls], out["steps"])
 
 
+def golden_pipeline_inference():
+    """The reference's own CausalInferencePipeline.inference (pipeline/causal_inference.py:48-277, the original Self-Forcing
+    driver: per block 4 denoise forwards, then one forward at context_noise that writes the clean K/V): tiny DiT, warped
+    denoising steps, 3 input frames (video extension, Step 2) + 2 generated blocks, cache of 32760 rows, stand-in VAE / text
+    encoder.  The re-noising uses torch.randn_like on the global generator (seed 77); the strides of its argument are
+    recorded so that a test can repeat the very same draws."""
+    import types
+    from oracle import standins
+    rs, CIP = ref_shim.load_release_server()
+    ref = ref_shim.load()
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    model.config = types.SimpleNamespace(num_heads=cfg["num_heads"], dim=cfg["dim"])
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.zeros(1, 512, TEXT_DIM, dtype=torch.bfloat16)
+    prompt[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+    noise = torch.randn(1, 6, 16, 60, 104, generator=g).to(torch.bfloat16)
+    initial = torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
+                                 independent_first_frame=False, context_noise=0)
+    pipe = CIP(args, "cpu", generator=wr, text_encoder=standins.StandinTextEncoder(prompt), vae=standins.StandinVAE())
+    draws = []
+    add_noise = pipe.scheduler.add_noise
+
+    def spy(x, eps, t):
+        draws.append((tuple(eps.shape), tuple(eps.stride()), float(eps.float().sum())))
+        return add_noise(x, eps, t)
+    pipe.scheduler.add_noise = spy
+    torch.manual_seed(77)
+    with torch.inference_mode():
+        video, latents = pipe.inference(noise, ["a prompt"], initial_latent=initial, return_latents=True)
+    out = {"prompt": prompt, "noise": noise, "initial": initial, "steps": pipe.denoising_step_list.clone(), "latents": latents.clone(),
+           "video_shape": tuple(video.shape), "video_sample": video[0, :, :, ::40, ::52].clone(), "draws": draws,
+           "indices": (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"])),
+           "kv_shape": tuple(pipe.kv_cache1[0]["k"].shape), "cache": cache_sample(pipe.kv_cache1)}
+    torch.save(out, os.path.join(OUT, "pipeline_inference_reference.pt"))
+    print("pipeline_inference_reference.pt", out["video_shape"], out["indices"], out["kv_shape"], draws[0][:2], out["steps"])
+
+
 def golden_t5():
     """Text encoder: the reference's own T5Encoder (wan/modules/t5.py:267-313, shared_pos=False like umt5_xxl,
     float32 like WanTextEncoder) at tiny dims with head_dim 64, two prompts of 29 and 48 tokens in a 48-slot window, plus
@@ -361,7 +402,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5", "session", "webcam"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5", "session", "webcam", "pipeline"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -378,3 +419,5 @@ if __name__ == "__main__":
         golden_session()
     if "webcam" in which:
         golden_session_webcam()
+    if "pipeline" in which:
+        golden_pipeline_inference()

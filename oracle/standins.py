@@ -47,6 +47,15 @@ def standin_encoder(frames, cache, stream=False):
     return z.unsqueeze(0), cache
 
 
+class StandinVAE:
+    """WanVAEWrapper.decode_to_pixel's contract (utils/wan_wrapper.py): latents [B, T, 16, h, w] -> pixels [B, T', 3, 8h, 8w]
+    in [-1, 1] with T' = 4T - 3 (whole-sequence decode, no cache)."""
+
+    def decode_to_pixel(self, latents, use_cache=False):
+        px, _ = standin_decoder(latents[:1], *([None] * 55))
+        return px
+
+
 class StandinTextEncoder:
     """WanTextEncoder's call contract (utils/wan_wrapper.py:43-56) returning fixed embeddings; `by_prompt` maps specific
     prompt strings to other embeddings (prompt transitions)."""

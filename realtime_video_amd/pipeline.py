@@ -38,6 +38,7 @@ class CausalInferencePipeline:
         self.independent_first_frame = getattr(args, "independent_first_frame", False)
         self.local_attn_size = self.generator.model.local_attn_size
         self.context_noise = getattr(args, "context_noise", 0)
+        self._randn_like = torch.randn_like     # re-noising draw of inference() (causal_inference.py:209); tests inject a stream
         if self.num_frame_per_block > 1:
             self.generator.model.num_frame_per_block = self.num_frame_per_block
 
@@ -137,7 +138,7 @@ class CausalInferencePipeline:
                 if index < len(steps) - 1:
                     next_timestep = steps[index + 1]
                     noisy_input = self.scheduler.add_noise(
-                        denoised_pred.flatten(0, 1), torch.randn_like(denoised_pred.flatten(0, 1)),
+                        denoised_pred.flatten(0, 1), self._randn_like(denoised_pred.flatten(0, 1)),
                         next_timestep * torch.ones([batch_size * nfpb], device=noise.device, dtype=torch.long)
                     ).unflatten(0, denoised_pred.shape[:2])
             output[:, current_start_frame:current_start_frame + nfpb] = denoised_pred

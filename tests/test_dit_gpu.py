@@ -684,3 +684,41 @@ def test_native_webcam_session_matches_reference_generation_session(golden):
     assert [(c[0], c[1]) for c in calls] == [(c[0], c[1]) for c in gold["encoder_calls"]]
     for ours, ref in zip(calls, gold["encoder_calls"]):
         assert max_abs(ours[2], ref[2]) <= 0.1
+
+
+def test_pipeline_inference_matches_reference_pipeline(golden):
+    """CausalInferencePipeline.inference - the drop-in boundary named by the north star (pipeline/causal_inference.py:48-277) -
+    against the golden minted by the reference's own class: 3 input frames cached at t = 0 (video extension), then 2 blocks of
+    4 warped denoising steps + the clean-context forward, KV cache of 32760 rows, stand-in VAE / text encoder.  Latents,
+    decoded video (in [0, 1]), schedule, cache indices and sampled cache rows."""
+    from oracle import standins
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    gold = golden("pipeline_inference_reference.pt")
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250],
+                                             warp_denoising_step=True, independent_first_frame=False, context_noise=0),
+                                   DEV, generator=wr, text_encoder=standins.StandinTextEncoder(gold["prompt"].to(DEV)),
+                                   vae=standins.StandinVAE())
+    assert torch.allclose(pipe.denoising_step_list.float(), gold["steps"].float())
+    torch.manual_seed(77)            # the reference re-noises with torch.randn_like on the global CPU generator
+    draws = []
+
+    def like(t):
+        eps = torch.randn_like(torch.empty(t.shape, dtype=torch.bfloat16))
+        draws.append((tuple(eps.shape), tuple(eps.stride()), float(eps.float().sum())))
+        return eps.to(t.device)
+    pipe._randn_like = like
+    video, latents = pipe.inference(gold["noise"].to(DEV), ["a prompt"], initial_latent=gold["initial"].to(DEV),
+                                    return_latents=True)
+    assert [d[:2] for d in draws] == [d[:2] for d in gold["draws"]]      # same noise stream (checksums: thread-count dependent sums)
+    assert all(abs(a[2] - b[2]) <= 1e-2 for a, b in zip(draws, gold["draws"]))
+    assert torch.equal(latents[:, :3].cpu(), gold["initial"])
+    assert rel_l2(latents.cpu(), gold["latents"]) <= 5e-2
+    assert tuple(video.shape) == gold["video_shape"] and float(video.min()) >= 0 and float(video.max()) <= 1
+    assert max_abs(video[0, :, :, ::40, ::52].cpu(), gold["video_sample"]) <= 0.1
+    assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"])) == gold["indices"]
+    assert tuple(pipe.kv_cache1[0]["k"].shape) == gold["kv_shape"]
+    _check_cache(pipe.kv_cache1, gold["cache"], tol=5e-2)
