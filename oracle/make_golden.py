@@ -372,6 +372,28 @@ def golden_pipeline_inference():
     print("pipeline_inference_reference.pt", out["video_shape"], out["indices"], out["kv_shape"], draws[0][:2], out["steps"])
 
 
+def golden_wan_vae_wrapper(ref):
+    """WanVAEWrapper.decode_to_pixel (utils/wan_wrapper.py:95-118 over WanVAE_.decode, wan/modules/vae.py:519-543): the
+    whole-sequence decode of CausalInferencePipeline.inference's Step 4, fp32 on the CPU, 3 latent frames of 8x12 -> 9 frames
+    of 64x96.  The wrapper is built without its checkpoint-loading __init__."""
+    from oracle import vae_oracle as vo
+    w = vo.make_vae_weights(seed=0)
+    W = ref.wan_wrapper.WanVAEWrapper
+    vae = W.__new__(W)
+    torch.nn.Module.__init__(vae)
+    vae.mean = torch.tensor(vo.MEAN, dtype=torch.float32)
+    vae.std = torch.tensor(vo.STD, dtype=torch.float32)
+    vae.model = ref.vae.WanVAE_(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                                temperal_downsample=[False, True, True], dropout=0.0).eval()
+    missing, unexpected = vae.model.load_state_dict(w, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") or k.startswith("conv1.") for k in missing), (missing[:4], unexpected)
+    z = vae_inputs()[0]                                           # [1, 3, 16, 8, 12]
+    with torch.inference_mode():
+        px = vae.decode_to_pixel(z, use_cache=False)
+    torch.save({"z": z, "pixels": px.clone()}, os.path.join(OUT, "wan_vae_wrapper.pt"))
+    print("wan_vae_wrapper.pt", tuple(px.shape), float(px.abs().mean()))
+
+
 def golden_t5():
     """Text encoder: the reference's own T5Encoder (wan/modules/t5.py:267-313, shared_pos=False like umt5_xxl,
     float32 like WanTextEncoder) at tiny dims with head_dim 64, two prompts of 29 and 48 tokens in a 48-slot window, plus
@@ -402,7 +424,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "t5", "session", "webcam", "pipeline"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "pipeline"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -413,6 +435,8 @@ if __name__ == "__main__":
         golden_vae(ref)
     if "vae_enc" in which:
         golden_vae_encoder(ref)
+    if "vae_wrapper" in which:
+        golden_wan_vae_wrapper(ref)
     if "t5" in which:
         golden_t5()
     if "session" in which:      # from here on load_release_server() has patched torch.cuda for the rest of the process

@@ -279,3 +279,54 @@ class VAEDecoderWrapper:
         return pixels.unsqueeze(0), cache
 
     __call__ = forward
+
+
+class WanVAEWrapper:
+    """Mirror of the reference's `WanVAEWrapper` (utils/wan_wrapper.py:58-118) for Step 4 of
+    `CausalInferencePipeline.inference` (pipeline/causal_inference.py:252): `decode_to_pixel(latent[B, T, 16, h, w],
+    use_cache=False)` -> pixels [B, T', 3, 8h, 8w] float32 in [-1, 1], T' = 4T - 3.  `WanVAE_.decode` (wan/modules/vae.py:
+    519-543) runs its decoder frame by frame over a cleared feature cache - the same computation as one streaming call on
+    fresh caches, which is what this delegates to.  `use_cache=True` (`cached_decode`, :545-567) keeps the caches across calls
+    until `clear_cache()`.  State-dict keys: the reference module's (`model.decoder.*`, `model.conv2.*`; the encoder half of
+    the checkpoint is ignored here - see vae_encoder.VAEEncoderWrapper)."""
+
+    def __init__(self, device="cuda"):
+        self.decoder = VAEDecoderWrapper(device)
+        self._caches = {}
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        inner = {}
+        for k, v in sd.items():
+            k = k[len("model."):] if k.startswith("model.") else k
+            if k.startswith("decoder.") or k.startswith("conv2."):
+                inner[k] = v
+        self.decoder.load_state_dict(inner, strict)
+        return self
+
+    def init_random_weights(self, seed=0):
+        self.decoder.init_random_weights(seed)
+        return self
+
+    def clear_cache(self):
+        self._caches = {}
+
+    def decode_to_pixel(self, latent, use_cache=False):
+        if use_cache and latent.shape[0] != 1:
+            raise AssertionError("Batch size must be 1 when using cache")       # wan_wrapper.py:100
+        out = []
+        for b in range(latent.shape[0]):
+            cache = self._caches.get(b, [None] * 55) if use_cache else [None] * 55
+            px, cache = self.decoder(latent[b:b + 1], *cache)
+            if use_cache:
+                self._caches[b] = cache
+            out.append(px[0])
+        return torch.stack(out, dim=0)

@@ -344,3 +344,26 @@ def test_full_size_decode_row_sharded_equals_unsharded():
             px, c = shard(z, *c)
             assert torch.equal(px, ref[:, :, :, r0:r1])
         del shard, c
+
+
+def test_wan_vae_wrapper_decode_to_pixel_matches_reference_golden(golden):
+    """The pipeline's `vae.decode_to_pixel` (utils/wan_wrapper.py:95-118) through the native streaming decoder vs the golden
+    minted from the reference's WanVAEWrapper (fp32): fp16 pipeline tolerance as for the streaming decoder; use_cache=True
+    continues the stream like WanVAE_.cached_decode."""
+    from oracle import vae_oracle as vo
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper, WanVAEWrapper
+    gold = golden("wan_vae_wrapper.pt")
+    w = vo.make_vae_weights(seed=0)
+    vae = WanVAEWrapper(DEV).load_state_dict({"model." + k: v for k, v in w.items()})
+    px = vae.decode_to_pixel(gold["z"].to(DEV), use_cache=False)
+    assert px.shape == gold["pixels"].shape and px.dtype == torch.float32
+    assert max_abs(px.cpu(), gold["pixels"]) <= 5e-2 and float((px.cpu() - gold["pixels"]).abs().mean()) <= 2e-3
+    # cached decode == the streaming wrapper fed the same two calls
+    ref = VAEDecoderWrapper(DEV)
+    ref.load_state_dict(w)
+    a, c = ref(gold["z"].to(DEV).half())
+    b, _ = ref(gold["z"].to(DEV).half().flip(1), *c)
+    assert torch.equal(vae.decode_to_pixel(gold["z"].to(DEV), use_cache=True), a)
+    assert torch.equal(vae.decode_to_pixel(gold["z"].to(DEV).flip(1), use_cache=True), b)
+    vae.clear_cache()
+    assert torch.equal(vae.decode_to_pixel(gold["z"].to(DEV), use_cache=True), a)

@@ -74,3 +74,15 @@ def test_frames_to_rgb8_known_values():
     assert out[0, :, 0].tolist() == [0, 255, 127, 255, 0, 191, 63, 128]
     assert out[0, :, 1].tolist() == [255, 0, 127, 0, 255, 63, 191, 127]
     assert torch.equal(out[0, :, 2], out[0, :, 0])
+
+
+def test_whole_sequence_decode_equals_streaming_decode_from_fresh_caches(golden):
+    """WanVAEWrapper.decode_to_pixel (the whole-sequence decode of pipeline.inference's Step 4: WanVAE_.decode, frame by frame
+    over a cleared cache) vs the streaming decoder oracle called once on fresh caches: the same computation, which is why the
+    native WanVAEWrapper facade delegates to the streaming decoder."""
+    from oracle import vae_oracle as vo
+    gold = golden("wan_vae_wrapper.pt")
+    w = vo.make_vae_weights(seed=0)
+    px, _ = vo.decoder_wrapper_forward(w, gold["z"], [None] * 55)
+    assert px.shape == gold["pixels"].shape == (1, 9, 3, 64, 96)
+    assert torch.allclose(px, gold["pixels"], atol=2e-5, rtol=1e-5)
