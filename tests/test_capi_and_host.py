@@ -197,3 +197,37 @@ def test_context_parallel_exchange_choice_and_cache_heads():
     assert m.kv_cache_heads() == 1
     m.context_parallel = OneRank(8, "rows")
     assert m.kv_cache_heads() == 8
+
+
+def test_attention_plugin_installs_into_the_reference_modules():
+    """INTEGRATION.md section 1 executed against the real reference (authoring container only; skipped where
+    /root/reference does not exist): after install() the reference's own CausalWanModel reaches this backend from its
+    self-attention and cross-attention call sites - shown by the backend's refusal of CPU tensors surfacing from the
+    reference's forward."""
+    import pytest
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree not present")
+    from oracle import wan_oracle as wo
+    from oracle.make_golden import TEXT_DIM, TINY, fresh_caches, tiny_inputs
+    from realtime_video_amd import attention as plug
+    ref = ref_shim.load()
+    mods = (ref.attention, ref.model, ref.cm)
+    saved = [{n: getattr(m, n) for n in ("attention", "sageattn_func", "SAGEATTN_AVAILABLE") if hasattr(m, n)} for m in mods]
+    plug.install(*mods)
+    try:
+        assert ref.attention.attention is plug.attention and ref.cm.attention is plug.attention
+        assert ref.model.SAGEATTN_AVAILABLE is True and ref.model.sageattn_func is plug.sageattn_func
+        cfg = dict(TINY, num_layers=1)
+        w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+        model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+        wr = ref_shim.build_reference_wrapper(ref, model)
+        lat, ctx = tiny_inputs()
+        kv, ca = fresh_caches(cfg, 4680)
+        with pytest.raises(RuntimeError, match="GPU|cuda|CUDA"):
+            with torch.inference_mode():
+                wr(lat[0], {"prompt_embeds": [ctx]}, torch.ones([1, 3], dtype=torch.int64) * 500, kv, ca, current_start=0)
+    finally:
+        for m, s in zip(mods, saved):
+            for n, v in s.items():
+                setattr(m, n, v)
