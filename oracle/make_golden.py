@@ -388,10 +388,16 @@ def golden_wan_vae_wrapper(ref):
     missing, unexpected = vae.model.load_state_dict(w, strict=False)
     assert not unexpected and all(k.startswith("encoder.") or k.startswith("conv1.") for k in missing), (missing[:4], unexpected)
     z = vae_inputs()[0]                                           # [1, 3, 16, 8, 12]
+    # encode_to_latent (:79-93 over WanVAE_.encode, vae.py:491-517) with the encoder weights of the encoder golden
+    we = vo.make_vae_encoder_weights(seed=1)
+    missing, unexpected = vae.model.load_state_dict(we, strict=False)
+    assert not unexpected
+    frames = torch.rand(1, 3, 9, 64, 96, generator=torch.Generator().manual_seed(34)) * 2 - 1
     with torch.inference_mode():
         px = vae.decode_to_pixel(z, use_cache=False)
-    torch.save({"z": z, "pixels": px.clone()}, os.path.join(OUT, "wan_vae_wrapper.pt"))
-    print("wan_vae_wrapper.pt", tuple(px.shape), float(px.abs().mean()))
+        lat = vae.encode_to_latent(frames)
+    torch.save({"z": z, "pixels": px.clone(), "frames": frames, "latents": lat.clone()}, os.path.join(OUT, "wan_vae_wrapper.pt"))
+    print("wan_vae_wrapper.pt", tuple(px.shape), float(px.abs().mean()), tuple(lat.shape), float(lat.abs().mean()))
 
 
 def golden_t5():

@@ -292,6 +292,9 @@ class WanVAEWrapper:
 
     def __init__(self, device="cuda"):
         self.decoder = VAEDecoderWrapper(device)
+        self.encoder = None            # built on first use (encode_to_latent is off the inference path)
+        self._enc_sd = None
+        self._device = device
         self._caches = {}
 
     def eval(self):
@@ -310,11 +313,26 @@ class WanVAEWrapper:
             if k.startswith("decoder.") or k.startswith("conv2."):
                 inner[k] = v
         self.decoder.load_state_dict(inner, strict)
+        enc = {k[len("model."):] if k.startswith("model.") else k: v for k, v in sd.items()}
+        self._enc_sd = {k: v for k, v in enc.items() if k.startswith("encoder.") or k.startswith("conv1.")} or None
+        self.encoder = None
         return self
 
     def init_random_weights(self, seed=0):
         self.decoder.init_random_weights(seed)
         return self
+
+    def encode_to_latent(self, pixel):
+        """utils/wan_wrapper.py:79-93: pixel [B, 3, T, H, W] in [-1, 1] (T = 1 + 4k) -> normalised latents [B, T', 16, h, w];
+        `WanVAE_.encode` (vae.py:491-517) chunks time 1, 4, 4, ... over a cleared cache = one non-streamed encoder call."""
+        from .vae_encoder import VAEEncoderWrapper
+        if self.encoder is None:
+            if self._enc_sd is None:
+                raise RuntimeError("encode_to_latent needs the encoder half of the VAE state dict (encoder.*, conv1.*)")
+            self.encoder = VAEEncoderWrapper(device=self._device)
+            self.encoder.load_state_dict(self._enc_sd)
+        out = [self.encoder(pixel[b:b + 1].half(), [None] * 55, stream=False)[0][0].float() for b in range(pixel.shape[0])]
+        return torch.stack(out, dim=0).permute(0, 2, 1, 3, 4)
 
     def clear_cache(self):
         self._caches = {}

@@ -367,3 +367,9 @@ def test_wan_vae_wrapper_decode_to_pixel_matches_reference_golden(golden):
     assert torch.equal(vae.decode_to_pixel(gold["z"].to(DEV).flip(1), use_cache=True), b)
     vae.clear_cache()
     assert torch.equal(vae.decode_to_pixel(gold["z"].to(DEV), use_cache=True), a)
+    # encode_to_latent (utils/wan_wrapper.py:79-93) through the native streaming encoder
+    we = vo.make_vae_encoder_weights(seed=1)
+    vae.load_state_dict({"model." + k: v for k, v in {**w, **we}.items()})
+    lat = vae.encode_to_latent(gold["frames"].to(DEV))
+    assert lat.shape == gold["latents"].shape and lat.dtype == torch.float32
+    assert max_abs(lat.cpu(), gold["latents"]) <= 3e-2 and rel_l2(lat.cpu(), gold["latents"]) <= 1e-2

@@ -86,3 +86,14 @@ def test_whole_sequence_decode_equals_streaming_decode_from_fresh_caches(golden)
     px, _ = vo.decoder_wrapper_forward(w, gold["z"], [None] * 55)
     assert px.shape == gold["pixels"].shape == (1, 9, 3, 64, 96)
     assert torch.allclose(px, gold["pixels"], atol=2e-5, rtol=1e-5)
+
+
+def test_whole_sequence_encode_equals_non_streamed_encoder_call(golden):
+    """WanVAEWrapper.encode_to_latent (WanVAE_.encode: chunks 1, 4, 4 over a cleared cache) vs the encoder-wrapper oracle
+    called once, non-streamed, on fresh caches."""
+    from oracle import vae_oracle as vo
+    gold = golden("wan_vae_wrapper.pt")
+    w = vo.make_vae_encoder_weights(seed=1)
+    mu, _ = vo.encoder_wrapper_forward(w, gold["frames"], [None] * 55, stream=False)
+    assert gold["latents"].shape == (1, 3, 16, 8, 12)
+    assert torch.allclose(mu.permute(0, 2, 1, 3, 4), gold["latents"], atol=2e-5, rtol=1e-5)
