@@ -351,53 +351,35 @@ def golden_pipeline_inference():
     prompt[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
     noise = torch.randn(1, 6, 16, 60, 104, generator=g).to(torch.bfloat16)
     initial = torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
-    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
-                                 independent_first_frame=False, context_noise=0)
-    pipe = CIP(args, "cpu", generator=wr, text_encoder=standins.StandinTextEncoder(prompt), vae=standins.StandinVAE())
-    draws = []
-    add_noise = pipe.scheduler.add_noise
+    def run(independent, noise, initial, seed):
+        args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=True, num_frame_per_block=3,
+                                     independent_first_frame=independent, context_noise=0)
+        pipe = CIP(args, "cpu", generator=wr, text_encoder=standins.StandinTextEncoder(prompt), vae=standins.StandinVAE())
+        draws = []
+        add_noise = pipe.scheduler.add_noise
 
-    def spy(x, eps, t):
-        draws.append((tuple(eps.shape), tuple(eps.stride()), float(eps.float().sum())))
-        return add_noise(x, eps, t)
-    pipe.scheduler.add_noise = spy
-    torch.manual_seed(77)
-    with torch.inference_mode():
-        video, latents = pipe.inference(noise, ["a prompt"], initial_latent=initial, return_latents=True)
-    out = {"prompt": prompt, "noise": noise, "initial": initial, "steps": pipe.denoising_step_list.clone(), "latents": latents.clone(),
-           "video_shape": tuple(video.shape), "video_sample": video[0, :, :, ::40, ::52].clone(), "draws": draws,
-           "indices": (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"])),
-           "kv_shape": tuple(pipe.kv_cache1[0]["k"].shape), "cache": cache_sample(pipe.kv_cache1)}
+        def spy(x, eps, t):
+            draws.append((tuple(eps.shape), tuple(eps.stride()), float(eps.float().sum())))
+            return add_noise(x, eps, t)
+        pipe.scheduler.add_noise = spy
+        torch.manual_seed(seed)
+        with torch.inference_mode():
+            video, latents = pipe.inference(noise, ["a prompt"], initial_latent=initial, return_latents=True)
+        pipe.scheduler.add_noise = add_noise
+        return {"noise": noise, "initial": initial, "steps": pipe.denoising_step_list.clone(), "latents": latents.clone(),
+                "video_shape": tuple(video.shape), "video_sample": video[0, :, :, ::40, ::52].clone(), "draws": draws,
+                "indices": (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"])),
+                "kv_shape": tuple(pipe.kv_cache1[0]["k"].shape), "cache": cache_sample(pipe.kv_cache1), "seed": seed,
+                "independent_first_frame": independent}
+
+    out = {"prompt": prompt}
+    out.update(run(False, noise, initial, 77))                                  # video extension: 3 input frames + 2 blocks
+    # independent first frame ([1, 3, ...] block structure, causal_inference.py:80-83, :139-154, :189-191):
+    out["t2v_independent"] = run(True, noise[:, :4].contiguous(), None, 78)     # 1 + 3 generated frames
+    out["i2v_independent"] = run(True, noise[:, :3].contiguous(), initial[:, :1].contiguous(), 79)   # 1 input frame + 1 block
     torch.save(out, os.path.join(OUT, "pipeline_inference_reference.pt"))
-    print("pipeline_inference_reference.pt", out["video_shape"], out["indices"], out["kv_shape"], draws[0][:2], out["steps"])
-
-
-def golden_wan_vae_wrapper(ref):
-    """WanVAEWrapper.decode_to_pixel (utils/wan_wrapper.py:95-118 over WanVAE_.decode, wan/modules/vae.py:519-543): the
-    whole-sequence decode of CausalInferencePipeline.inference's Step 4, fp32 on the CPU, 3 latent frames of 8x12 -> 9 frames
-    of 64x96.  The wrapper is built without its checkpoint-loading __init__."""
-    from oracle import vae_oracle as vo
-    w = vo.make_vae_weights(seed=0)
-    W = ref.wan_wrapper.WanVAEWrapper
-    vae = W.__new__(W)
-    torch.nn.Module.__init__(vae)
-    vae.mean = torch.tensor(vo.MEAN, dtype=torch.float32)
-    vae.std = torch.tensor(vo.STD, dtype=torch.float32)
-    vae.model = ref.vae.WanVAE_(dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
-                                temperal_downsample=[False, True, True], dropout=0.0).eval()
-    missing, unexpected = vae.model.load_state_dict(w, strict=False)
-    assert not unexpected and all(k.startswith("encoder.") or k.startswith("conv1.") for k in missing), (missing[:4], unexpected)
-    z = vae_inputs()[0]                                           # [1, 3, 16, 8, 12]
-    # encode_to_latent (:79-93 over WanVAE_.encode, vae.py:491-517) with the encoder weights of the encoder golden
-    we = vo.make_vae_encoder_weights(seed=1)
-    missing, unexpected = vae.model.load_state_dict(we, strict=False)
-    assert not unexpected
-    frames = torch.rand(1, 3, 9, 64, 96, generator=torch.Generator().manual_seed(34)) * 2 - 1
-    with torch.inference_mode():
-        px = vae.decode_to_pixel(z, use_cache=False)
-        lat = vae.encode_to_latent(frames)
-    torch.save({"z": z, "pixels": px.clone(), "frames": frames, "latents": lat.clone()}, os.path.join(OUT, "wan_vae_wrapper.pt"))
-    print("wan_vae_wrapper.pt", tuple(px.shape), float(px.abs().mean()), tuple(lat.shape), float(lat.abs().mean()))
+    print("pipeline_inference_reference.pt", out["video_shape"], out["indices"], out["t2v_independent"]["indices"],
+          out["i2v_independent"]["indices"], out["t2v_independent"]["video_shape"])
 
 
 def golden_t5():

@@ -93,10 +93,12 @@ class CausalInferencePipeline:
         `context_noise` that writes the clean K/V into the cache (:227-236)."""
         batch_size, num_frames, num_channels, height, width = noise.shape
         nfpb = self.num_frame_per_block
-        if self.independent_first_frame and initial_latent is None:
-            raise NotImplementedError("independent_first_frame without an initial latent")
-        assert num_frames % nfpb == 0
-        num_blocks = num_frames // nfpb
+        if not self.independent_first_frame or initial_latent is not None:
+            assert num_frames % nfpb == 0
+            num_blocks = num_frames // nfpb
+        else:   # a [1, n, n, ...] model generating without image conditioning (causal_inference.py:80-83)
+            assert (num_frames - 1) % nfpb == 0
+            num_blocks = (num_frames - 1) // nfpb
         num_input_frames = initial_latent.shape[1] if initial_latent is not None else 0
         conditional_dict = self.text_encoder(text_prompts=text_prompts)
         output = torch.zeros([batch_size, num_frames + num_input_frames, num_channels, height, width],
@@ -112,25 +114,40 @@ class CausalInferencePipeline:
                 c["local_end_index"] = 0
         events = []
         current_start_frame = 0
+
+        def cache_context(ref):     # Step 2: clean frames at t = 0 only fill the KV cache
+            timestep = torch.zeros([batch_size, ref.shape[1]], device=noise.device, dtype=torch.int64)
+            self.generator(noisy_image_or_video=ref, conditional_dict=conditional_dict, timestep=timestep,
+                           kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
+                           current_start=current_start_frame * self.frame_seq_length)
+
         if initial_latent is not None:
-            timestep = torch.zeros([batch_size, nfpb], device=noise.device, dtype=torch.int64)
-            assert num_input_frames % nfpb == 0
-            for _ in range(num_input_frames // nfpb):
+            if self.independent_first_frame:   # 1 + nfpb * k input frames (:139-154)
+                assert (num_input_frames - 1) % nfpb == 0
+                num_input_blocks = (num_input_frames - 1) // nfpb
+                output[:, :1] = initial_latent[:, :1]
+                cache_context(initial_latent[:, :1])
+                current_start_frame += 1
+            else:
+                assert num_input_frames % nfpb == 0
+                num_input_blocks = num_input_frames // nfpb
+            for _ in range(num_input_blocks):
                 ref = initial_latent[:, current_start_frame:current_start_frame + nfpb]
                 output[:, current_start_frame:current_start_frame + nfpb] = ref
-                self.generator(noisy_image_or_video=ref, conditional_dict=conditional_dict, timestep=timestep,
-                               kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
-                               current_start=current_start_frame * self.frame_seq_length)
+                cache_context(ref)
                 current_start_frame += nfpb
+        all_num_frames = [nfpb] * num_blocks
+        if self.independent_first_frame and initial_latent is None:
+            all_num_frames = [1] + all_num_frames
         steps = self.denoising_step_list.to(noise.device)
-        for _ in range(num_blocks):
+        for cur in all_num_frames:
             if profile:
                 s = torch.cuda.Event(enable_timing=True)
                 s.record()
             lo = current_start_frame - num_input_frames
-            noisy_input = noise[:, lo:lo + nfpb]
+            noisy_input = noise[:, lo:lo + cur]
             for index, current_timestep in enumerate(steps):
-                timestep = torch.ones([batch_size, nfpb], device=noise.device, dtype=torch.int64) * current_timestep
+                timestep = torch.ones([batch_size, cur], device=noise.device, dtype=torch.int64) * current_timestep
                 _, denoised_pred = self.generator(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
                                                   timestep=timestep, kv_cache=self.kv_cache1,
                                                   crossattn_cache=self.crossattn_cache,
@@ -139,9 +156,9 @@ class CausalInferencePipeline:
                     next_timestep = steps[index + 1]
                     noisy_input = self.scheduler.add_noise(
                         denoised_pred.flatten(0, 1), self._randn_like(denoised_pred.flatten(0, 1)),
-                        next_timestep * torch.ones([batch_size * nfpb], device=noise.device, dtype=torch.long)
+                        next_timestep * torch.ones([batch_size * cur], device=noise.device, dtype=torch.long)
                     ).unflatten(0, denoised_pred.shape[:2])
-            output[:, current_start_frame:current_start_frame + nfpb] = denoised_pred
+            output[:, current_start_frame:current_start_frame + cur] = denoised_pred
             context_timestep = torch.ones_like(timestep) * self.context_noise
             self.generator(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict,
                            timestep=context_timestep, kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
@@ -150,7 +167,7 @@ class CausalInferencePipeline:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 events.append((s, e))
-            current_start_frame += nfpb
+            current_start_frame += cur
         if profile:
             torch.cuda.synchronize()
             self.block_times_ms = [s.elapsed_time(e) for s, e in events]

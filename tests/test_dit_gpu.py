@@ -686,24 +686,28 @@ def test_native_webcam_session_matches_reference_generation_session(golden):
         assert max_abs(ours[2], ref[2]) <= 0.1
 
 
-def test_pipeline_inference_matches_reference_pipeline(golden):
+@pytest.mark.parametrize("variant", ["extension", "t2v_independent", "i2v_independent"])
+def test_pipeline_inference_matches_reference_pipeline(golden, variant):
     """CausalInferencePipeline.inference - the drop-in boundary named by the north star (pipeline/causal_inference.py:48-277) -
-    against the golden minted by the reference's own class: 3 input frames cached at t = 0 (video extension), then 2 blocks of
-    4 warped denoising steps + the clean-context forward, KV cache of 32760 rows, stand-in VAE / text encoder.  Latents,
+    against goldens minted by the reference's own class: "extension" = 3 input frames cached at t = 0, then 2 blocks of 4 warped
+    denoising steps + the clean-context forward; "t2v_independent" / "i2v_independent" = the independent-first-frame block
+    structure [1, 3] without / with a 1-frame image latent.  KV cache of 32760 rows, stand-in VAE / text encoder.  Latents,
     decoded video (in [0, 1]), schedule, cache indices and sampled cache rows."""
     from oracle import standins
     from oracle import wan_oracle as wo
     from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
-    gold = golden("pipeline_inference_reference.pt")
+    top = golden("pipeline_inference_reference.pt")
+    gold = top if variant == "extension" else top[variant]
     cfg, text_dim, _ = _tiny()
     w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
     model, wr = _build(cfg, text_dim, w)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250],
-                                             warp_denoising_step=True, independent_first_frame=False, context_noise=0),
-                                   DEV, generator=wr, text_encoder=standins.StandinTextEncoder(gold["prompt"].to(DEV)),
+                                             warp_denoising_step=True, independent_first_frame=variant != "extension",
+                                             context_noise=0),
+                                   DEV, generator=wr, text_encoder=standins.StandinTextEncoder(top["prompt"].to(DEV)),
                                    vae=standins.StandinVAE())
     assert torch.allclose(pipe.denoising_step_list.float(), gold["steps"].float())
-    torch.manual_seed(77)            # the reference re-noises with torch.randn_like on the global CPU generator
+    torch.manual_seed(gold.get("seed", 77))   # the reference re-noises with torch.randn_like on the global CPU generator
     draws = []
 
     def like(t):
@@ -711,11 +715,12 @@ def test_pipeline_inference_matches_reference_pipeline(golden):
         draws.append((tuple(eps.shape), tuple(eps.stride()), float(eps.float().sum())))
         return eps.to(t.device)
     pipe._randn_like = like
-    video, latents = pipe.inference(gold["noise"].to(DEV), ["a prompt"], initial_latent=gold["initial"].to(DEV),
-                                    return_latents=True)
+    initial = gold["initial"].to(DEV) if gold["initial"] is not None else None
+    video, latents = pipe.inference(gold["noise"].to(DEV), ["a prompt"], initial_latent=initial, return_latents=True)
     assert [d[:2] for d in draws] == [d[:2] for d in gold["draws"]]      # same noise stream (checksums: thread-count dependent sums)
     assert all(abs(a[2] - b[2]) <= 1e-2 for a, b in zip(draws, gold["draws"]))
-    assert torch.equal(latents[:, :3].cpu(), gold["initial"])
+    if initial is not None:
+        assert torch.equal(latents[:, :initial.shape[1]].cpu(), gold["initial"])
     assert rel_l2(latents.cpu(), gold["latents"]) <= 5e-2
     assert tuple(video.shape) == gold["video_shape"] and float(video.min()) >= 0 and float(video.max()) <= 1
     assert max_abs(video[0, :, :, ::40, ::52].cpu(), gold["video_sample"]) <= 0.1
