@@ -260,6 +260,65 @@ def golden_session():
     print("session_reference.pt", out["indices"], out["pixels_shape"], out["encoder_input_shapes"])
 
 
+def start_image(seed=41):
+    """The start frame of the image-to-video golden: a smooth 832x480 8-bit RGB image."""
+    import numpy as np
+    from PIL import Image
+    low = torch.rand(1, 3, 15, 26, generator=torch.Generator().manual_seed(seed))
+    img = torch.nn.functional.interpolate(low, size=(480, 832), mode="bilinear")[0]
+    return Image.fromarray((img.permute(1, 2, 0) * 255).round().to(torch.uint8).numpy(), "RGB")
+
+
+def golden_session_start_frame():
+    """The reference's GenerationSession started from an image (params.start_frame -> setup_start_frame,
+    release_server.py:429-431, :578-586; block 0 resumes from the encoded frames, :590-595): 2 blocks behind the 3 encoded
+    latent frames, c = 3, 4 steps, stand-in VAE / text encoder."""
+    import types
+    from oracle import standins
+    rs, CIP = ref_shim.load_release_server()
+    ref = ref_shim.load()
+    orig_to = torch.Tensor.to
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if isinstance(x, str) and x.startswith("cuda") else x for x in a)
+        return orig_to(self, *a, **k)
+    torch.Tensor.to = to_cpu
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    model.config = types.SimpleNamespace(num_heads=cfg["num_heads"], dim=cfg["dim"])
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.zeros(1, 512, TEXT_DIM, dtype=torch.bfloat16)
+    prompt[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+    text = standins.StandinTextEncoder(prompt)
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=False, num_frame_per_block=3,
+                                 independent_first_frame=False)
+    pipe = CIP(args, "cpu", generator=wr, text_encoder=text, vae=object())
+    enc_calls = []
+
+    def encoder(frames, cache, stream=False):
+        enc_calls.append((tuple(frames.shape), bool(stream), frames.float()[..., ::40, ::52].clone()))
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = rs.Models(text, wr, pipe, encoder, standins.standin_decoder)
+    params = rs.GenerateParams(prompt="synthetic", seed=9, num_blocks=3, num_denoising_steps=4, kv_cache_num_frames=3,
+                               keep_first_frame=False)
+    params.start_frame = start_image()        # the server assigns the decoded PIL image the same way (:944-946)
+    sess = rs.GenerationSession(params, types.SimpleNamespace(use_taehv=False), frame_callback=lambda *a, **k: None, models=models)
+    out = {"prompt": prompt, "noise": sess.noise.clone(), "resume_latents": sess.resume_latents.clone(), "blocks": [], "indices": []}
+    for b in range(2):
+        sess.generate_block_internal(models)
+        out["blocks"].append(sess.last_pred.clone())
+        out["indices"].append((int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                               sess.current_start_frame, sess.block_idx, sess.total_frames_sent))
+    out["all_latents"] = sess.all_latents.clone()
+    out["encoder_calls"] = enc_calls
+    torch.Tensor.to = orig_to
+    torch.save(out, os.path.join(OUT, "session_start_frame_reference.pt"))
+    print("session_start_frame_reference.pt", out["indices"], tuple(out["resume_latents"].shape), [(c[0], c[1]) for c in enc_calls])
+
+
 def webcam_frames(seed=31, counts=(11, 12, 14)):
     """Input frames of the webcam golden: per block a list of [3, 480, 832] fp16 frames in [-1, 1] (smooth in space so that
     the stand-in encoder's pooling is well conditioned)."""
@@ -412,7 +471,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "pipeline"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "start_frame", "pipeline"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -431,5 +490,7 @@ if __name__ == "__main__":
         golden_session()
     if "webcam" in which:
         golden_session_webcam()
+    if "start_frame" in which:
+        golden_session_start_frame()
     if "pipeline" in which:
         golden_pipeline_inference()

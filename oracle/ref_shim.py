@@ -180,6 +180,11 @@ def load_release_server():
     sys.modules["omegaconf"].OmegaConf = type("OmegaConf", (), {})
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+
+    def to_tensor(pic):     # torchvision.transforms.functional.to_tensor for 8-bit RGB PIL images (published semantics)
+        import numpy as np
+        return torch.from_numpy(np.asarray(pic).copy()).permute(2, 0, 1).to(torch.float32).div(255)
+    sys.modules["torchvision.transforms.functional"].to_tensor = to_tensor
     # the HTTP / WebSocket layer below the session class is control plane: its decorators become no-ops
     class _App:
         def __init__(self, *a, **k):

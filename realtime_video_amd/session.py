@@ -30,6 +30,7 @@ class GenerateParams:
     context_noise: float = 0.0
     keep_first_frame: bool = False
     webcam_mode: bool = False          # streaming video-to-video: incoming frames are VAE-encoded every block
+    start_frame: object = None         # image-to-video start: PIL image or [3, H, W] tensor in [0, 1] (release_server.py:578-586)
     interp_blocks: int = -1
     kv_cache_num_frames: int = 3
     num_blocks: int = 9
@@ -89,6 +90,26 @@ class GenerationSession:
         self.init_models(models, params)
         self.denoising_step_list = get_denoising_schedule(self.zero_padded_timesteps, params.strength,
                                                           steps=params.num_denoising_steps)
+        if params.start_frame is not None:            # release_server.py:429-431
+            self.setup_start_frame(params.start_frame, models)
+
+    # release_server.py:578-586
+    def setup_start_frame(self, image, models):
+        """Image-to-video start: the image, repeated over the whole pixel context window (1 + (c-1)*4 frames), is encoded
+        and becomes `resume_latents` - block 0 then recomputes the KV cache from it and generation continues behind it.
+        `image`: PIL image, or the [3, H, W] tensor in [0, 1] torchvision's to_tensor would make of it."""
+        if models.vae_encoder is None:
+            raise RuntimeError("start_frame needs a VAE encoder")
+        if not torch.is_tensor(image):
+            import numpy as np
+            arr = np.asarray(image.convert("RGB"))
+            image = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255)      # TF.to_tensor
+        frame_cache_len = 1 + (self.params.kv_cache_num_frames - 1) * 4
+        tensor = image.to(dtype=torch.float16).to(self.gpu).sub_(0.5).mul_(2.0)
+        tensors = torch.stack([tensor] * frame_cache_len)
+        latents = encode_video_latent(models.vae_encoder, [None] * 55, resample_to=16, max_frames=81, video_path_or_url=None,
+                                      frames=tensors, height=self.height, width=self.width, stream=False)[0]
+        self.resume_latents = latents.transpose(0, 1)[None]
 
     def _randn(self, shape):
         """Re-noising draw of release_server.py:692 (bf16 from the session generator); a hook so tests can

@@ -727,3 +727,44 @@ def test_pipeline_inference_matches_reference_pipeline(golden, variant):
     assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"])) == gold["indices"]
     assert tuple(pipe.kv_cache1[0]["k"].shape) == gold["kv_shape"]
     _check_cache(pipe.kv_cache1, gold["cache"], tol=5e-2)
+
+
+def test_native_session_start_frame_matches_reference_generation_session(golden):
+    """Image-to-video start (params.start_frame -> setup_start_frame -> resume_latents, release_server.py:429-431, :578-595)
+    against the golden minted by the reference's GenerationSession: the 9-frame encoder call, the resumed latents, two
+    generated blocks behind them, indices and frame accounting."""
+    from oracle import standins
+    from oracle import wan_oracle as wo
+    from oracle.make_golden import start_image
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models
+    gold = golden("session_start_frame_reference.pt")
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
+                                   DEV, generator=wr, text_encoder=None, vae=None)
+    calls = []
+
+    def encoder(frames, cache, stream=False):
+        calls.append((tuple(frames.shape), bool(stream), frames.float()[..., ::40, ::52].cpu()))
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=standins.StandinTextEncoder(gold["prompt"].to(DEV)),
+                    vae_decoder=standins.standin_decoder, vae_encoder=encoder)
+    sess = GenerationSession(GenerateParams(seed=9, num_blocks=3, num_denoising_steps=4, kv_cache_num_frames=3,
+                                            keep_first_frame=False, start_frame=start_image()), models, device=DEV)
+    assert max_abs(sess.resume_latents.float().cpu(), gold["resume_latents"].float()) <= 2e-2
+    cpu_rnd = torch.Generator().manual_seed(9)
+    noise = torch.randn([1, 9, 16, 60, 104], dtype=torch.bfloat16, generator=cpu_rnd)
+    assert torch.equal(noise, gold["noise"])
+    sess.noise = noise.to(DEV)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    for b in range(2):
+        sess.generate_block()
+        assert rel_l2(sess.last_pred.cpu(), gold["blocks"][b]) <= 5e-2, b
+        assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                sess.current_start_frame, sess.block_idx, sess.total_frames_sent) == gold["indices"][b]
+    assert rel_l2(sess.all_latents.cpu(), gold["all_latents"]) <= 5e-2
+    assert [(c[0], c[1]) for c in calls] == [(c[0], c[1]) for c in gold["encoder_calls"]]
+    assert max_abs(calls[0][2], gold["encoder_calls"][0][2]) <= 2e-2
