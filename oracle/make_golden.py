@@ -319,6 +319,58 @@ def golden_session_start_frame():
     print("session_start_frame_reference.pt", out["indices"], tuple(out["resume_latents"].shape), [(c[0], c[1]) for c in enc_calls])
 
 
+def v2v_video(seed=51, T=33):
+    """The input video of the offline v2v golden: [T, 3, 480, 832] float32 in [-1, 1], smooth in space."""
+    low = torch.rand(T, 3, 15, 26, generator=torch.Generator().manual_seed(seed)) * 2 - 1
+    return torch.nn.functional.interpolate(low, size=(480, 832), mode="bilinear")
+
+
+def golden_session_v2v():
+    """The reference's GenerationSession with `input_video` (offline video-to-video, release_server.py:417-428, :529-540;
+    v2v.py:138-158): the decoded video (33 frames; v2v.load_video_as_rgb - cv2 / ffmpeg file decoding, control plane - is
+    replaced by the in-memory frames) is encoded once, noised to the first step's level with the session generator, and
+    bounds the block count (9 latent frames -> 2 blocks); strength 0.6, 4 steps."""
+    import types
+    from oracle import standins
+    rs, CIP = ref_shim.load_release_server()
+    ref = ref_shim.load()
+    video = v2v_video()
+    sys.modules["v2v"].load_video_as_rgb = lambda path, **k: video.clone()
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    model = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+    model.config = types.SimpleNamespace(num_heads=cfg["num_heads"], dim=cfg["dim"])
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.zeros(1, 512, TEXT_DIM, dtype=torch.bfloat16)
+    prompt[0, :64] = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+    text = standins.StandinTextEncoder(prompt)
+    args = types.SimpleNamespace(denoising_step_list=[1000, 750, 500, 250], warp_denoising_step=False, num_frame_per_block=3,
+                                 independent_first_frame=False)
+    pipe = CIP(args, "cpu", generator=wr, text_encoder=text, vae=object())
+    enc_calls = []
+
+    def encoder(frames, cache, stream=False):
+        enc_calls.append((tuple(frames.shape), bool(stream)))
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = rs.Models(text, wr, pipe, encoder, standins.standin_decoder)
+    params = rs.GenerateParams(prompt="synthetic", seed=9, num_blocks=5, num_denoising_steps=4, kv_cache_num_frames=3,
+                               keep_first_frame=True, input_video="memory://video", strength=0.6)
+    sess = rs.GenerationSession(params, types.SimpleNamespace(use_taehv=False), frame_callback=lambda *a, **k: None, models=models)
+    out = {"prompt": prompt, "noise": sess.noise.clone(), "num_blocks": sess.num_blocks, "steps": sess.denoising_step_list.clone(),
+           "blocks": [], "indices": []}
+    for b in range(sess.num_blocks):
+        sess.generate_block_internal(models)
+        out["blocks"].append(sess.last_pred.clone())
+        out["indices"].append((int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                               sess.current_start_frame, sess.block_idx, sess.total_frames_sent))
+    assert sess.generate_block_internal(models) is None
+    out["encoder_calls"] = enc_calls
+    torch.save(out, os.path.join(OUT, "session_v2v_reference.pt"))
+    print("session_v2v_reference.pt", out["num_blocks"], out["indices"], tuple(out["noise"].shape), enc_calls, out["steps"])
+
+
 def webcam_frames(seed=31, counts=(11, 12, 14)):
     """Input frames of the webcam golden: per block a list of [3, 480, 832] fp16 frames in [-1, 1] (smooth in space so that
     the stand-in encoder's pooling is well conditioned)."""
@@ -471,7 +523,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "start_frame", "pipeline"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "start_frame", "v2v", "pipeline"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -492,5 +544,7 @@ if __name__ == "__main__":
         golden_session_webcam()
     if "start_frame" in which:
         golden_session_start_frame()
+    if "v2v" in which:
+        golden_session_v2v()
     if "pipeline" in which:
         golden_pipeline_inference()

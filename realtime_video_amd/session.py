@@ -30,6 +30,8 @@ class GenerateParams:
     context_noise: float = 0.0
     keep_first_frame: bool = False
     webcam_mode: bool = False          # streaming video-to-video: incoming frames are VAE-encoded every block
+    input_frames: object = None        # offline video-to-video: the decoded input video [T, 3, H, W] in [-1, 1] (the reference's
+                                       # `input_video` path / URL after load_video_as_rgb, v2v.py:33-131; file decoding is out of scope)
     start_frame: object = None         # image-to-video start: PIL image or [3, H, W] tensor in [0, 1] (release_server.py:578-586)
     interp_blocks: int = -1
     kv_cache_num_frames: int = 3
@@ -90,8 +92,23 @@ class GenerationSession:
         self.init_models(models, params)
         self.denoising_step_list = get_denoising_schedule(self.zero_padded_timesteps, params.strength,
                                                           steps=params.num_denoising_steps)
+        if params.input_frames is not None:           # release_server.py:417-428
+            self.setup_input_video(params.input_frames, models)
         if params.start_frame is not None:            # release_server.py:429-431
             self.setup_start_frame(params.start_frame, models)
+
+    # release_server.py:417-428 (+ :529-540 encode_v2v)
+    def setup_input_video(self, frames, models):
+        """Offline video-to-video: the video's latents, noised to the first step's level with the session generator, replace
+        the noise; the block count follows the video (latent frames / 3 - 1, capped by params.num_blocks)."""
+        if models.vae_encoder is None:
+            raise RuntimeError("input_frames needs a VAE encoder")
+        s0 = self.denoising_step_list[0] / 1000
+        latents, _ = encode_video_latent(models.vae_encoder, [None] * 55, frames=frames.to(self.gpu), height=self.params.height,
+                                         width=self.params.width, stream=False, max_frames=None, resample_to=None)
+        latents = latents[None].to(self.gpu, dtype=self.noise.dtype).movedim(1, 2)
+        self.noise = (latents * (1.0 - s0) + self._randn(latents.shape) * s0).contiguous()
+        self.num_blocks = min(latents.shape[1] // self.num_frame_per_block - 1, self.params.num_blocks)
 
     # release_server.py:578-586
     def setup_start_frame(self, image, models):

@@ -768,3 +768,44 @@ def test_native_session_start_frame_matches_reference_generation_session(golden)
     assert rel_l2(sess.all_latents.cpu(), gold["all_latents"]) <= 5e-2
     assert [(c[0], c[1]) for c in calls] == [(c[0], c[1]) for c in gold["encoder_calls"]]
     assert max_abs(calls[0][2], gold["encoder_calls"][0][2]) <= 2e-2
+
+
+def test_native_session_offline_v2v_matches_reference_generation_session(golden):
+    """Offline video-to-video (`input_video`, release_server.py:417-428) against the golden minted by the reference's
+    GenerationSession: one non-streamed encoder call over the 33-frame video, noise = latents noised to the first step's
+    level from the session generator, block count bounded by the video (2), two generated blocks."""
+    from oracle import standins
+    from oracle import wan_oracle as wo
+    from oracle.make_golden import v2v_video
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models
+    gold = golden("session_v2v_reference.pt")
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    model, wr = _build(cfg, text_dim, w)
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
+                                   DEV, generator=wr, text_encoder=None, vae=None)
+    calls = []
+
+    def encoder(frames, cache, stream=False):
+        calls.append((tuple(frames.shape), bool(stream)))
+        return standins.standin_encoder(frames, cache, stream)
+
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=standins.StandinTextEncoder(gold["prompt"].to(DEV)),
+                    vae_decoder=standins.standin_decoder, vae_encoder=encoder)
+    sess = GenerationSession(GenerateParams(seed=9, num_blocks=5, num_denoising_steps=4, kv_cache_num_frames=3,
+                                            keep_first_frame=True, strength=0.6), models, device=DEV)
+    assert torch.allclose(sess.denoising_step_list.cpu().float(), gold["steps"].float())
+    cpu_rnd = torch.Generator().manual_seed(9)
+    torch.randn([1, 15, 16, 60, 104], dtype=torch.bfloat16, generator=cpu_rnd)       # the session's initial noise comes first
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    sess.setup_input_video(v2v_video(), models)       # what GenerateParams(input_frames=...) runs inside __init__
+    assert sess.num_blocks == gold["num_blocks"] == 2 and calls == gold["encoder_calls"]
+    # same draws, same formula; the stand-in encoder's fp32 sums differ in the last bit between CPU and GPU -> single bf16 ulps
+    assert rel_l2(sess.noise.cpu(), gold["noise"]) <= 2e-3 and max_abs(sess.noise.float().cpu(), gold["noise"].float()) <= 0.07
+    for b in range(2):
+        sess.generate_block()
+        assert rel_l2(sess.last_pred.cpu(), gold["blocks"][b]) <= 5e-2, b
+        assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"]),
+                sess.current_start_frame, sess.block_idx, sess.total_frames_sent) == gold["indices"][b]
+    assert sess.generate_block_internal(models) is None
