@@ -429,3 +429,54 @@ def test_attention_full_size_properties(ops):
     v2 = torch.cat([v[:, :, hs], v[:, :, hs]], 1).contiguous()
     out_d = ops.attn_fwd(q[:, :, hs].contiguous(), k2, v2)
     assert rel_l2(out_d, out[:, :, hs]) <= 5e-3
+
+
+# ----------------------------------------------------------------------------------------- randomized shape sweeps
+def test_gemm_random_shape_sweep(ops):
+    """40 random problems (ragged M incl. 1, N multiple of 8, K multiple of 64, every epilogue combination, default tile
+    config with the split-K workspace attached) against the fp32 eager chain."""
+    import random
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    rng = random.Random(1234)
+    for case in range(40):
+        M = rng.choice([1, 2, 3, 31, 255, 257, 585, 1170, rng.randint(1, 5000)])
+        N = 8 * rng.randint(1, 700)
+        K = 64 * rng.randint(1, 40)
+        act = rng.choice([0, 0, 1, 2])
+        a, w = _randn(M, K, seed=case), _randn(N, K, seed=100 + case, scale=K ** -0.5)
+        b = _randn(N, seed=200 + case, scale=0.1) if rng.random() < 0.7 else None
+        rpf = rng.choice([1, 7, 1560])
+        use_gate = rng.random() < 0.4
+        gate = _randn((M + rpf - 1) // rpf, N, seed=300 + case) if use_gate else None
+        res = _randn(M, N, seed=400 + case) if rng.random() < 0.4 else None
+        out = ops.gemm(a, w, bias=b, act=act, gate=gate, gate_stride=N if use_gate else 0,
+                       rows_per_frame=rpf if use_gate else 0, residual=res)
+        ref = _gemm_ref(a, w, b, act, gate, rpf, res)
+        assert rel_l2(out, ref) <= 5e-3, (case, M, N, K, act, use_gate, res is not None)
+        assert max_abs(out, ref) <= 0.05 * float(ref.float().abs().max()) + 1e-2, (case, M, N, K)
+
+
+def test_attention_random_shape_sweep(ops):
+    """30 random problems: ragged Lq / Lkv (incl. 1), 1..5 heads, strided cache views, dense and block-causal with random
+    block size / query offset, against the fp32 definition."""
+    import random
+    rng = random.Random(4321)
+    for case in range(30):
+        H = rng.randint(1, 5)
+        Lq = rng.choice([1, 31, 32, 33, 255, 256, 257, rng.randint(1, 1500)])
+        Lkv = rng.choice([1, 63, 64, 65, rng.randint(1, 3000)])
+        q = _randn(1, Lq, H, 128, seed=case)
+        cache_k, cache_v = _randn(1, Lkv + 9, H, 128, seed=50 + case), _randn(1, Lkv + 9, H, 128, seed=90 + case)
+        off = rng.randint(0, 9)
+        k, v = cache_k[:, off:off + Lkv], cache_v[:, off:off + Lkv]
+        if rng.random() < 0.4 and Lkv >= Lq:
+            cb = rng.choice([8, 96, 128, 520])
+            q_off = rng.randint(0, Lkv - Lq)
+            lim = ((q_off + torch.arange(Lq, device=DEV)) // cb + 1) * cb
+            out = ops.attn_fwd(q, k, v, causal_block=cb, q_offset=q_off)
+            ref = _attn_ref(q, k, v, kv_limit=lim.clamp(max=Lkv))
+        else:
+            out = ops.attn_fwd(q, k, v)
+            ref = _attn_ref(q, k, v)
+        assert max_abs(out, ref) <= 2.5e-2, (case, Lq, Lkv, H)
+        assert rel_l2(out, ref) <= 1.2e-2, (case, Lq, Lkv, H)
