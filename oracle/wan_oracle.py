@@ -414,8 +414,17 @@ class SessionOracle:
     The VAE decode / first-frame re-encode legs are separate (oracle/vae_oracle.py)."""
 
     def __init__(self, w, cfg, prompt_embeds, noise, kv_cache_num_frames=3, num_steps=4, shift=5.0,
-                 seed=0, attn_fn=None, first_frame_fn=None):
+                 seed=0, attn_fn=None, first_frame_fn=None, strength=1.0, webcam_encoder=None, num_blocks=None):
+        """`webcam_encoder`: callable with VAEEncoderWrapper's contract; passing it switches the session to webcam (streaming
+        v2v) mode (release_server.py:489-527, :651-657).  `strength` only matters with an input video / webcam (:365-366)."""
         self.w, self.cfg, self.attn_fn = w, cfg, attn_fn
+        self.webcam_encoder = webcam_encoder
+        self.frame_queue = []                       # webcam frames [3, H, W] in [-1, 1] (:470-487 after decoding)
+        self.encode_vae_cache = [None] * 55
+        self.interpolated_prompt_embeds = []
+        self.resume_latents = None
+        self.randn_like = torch.randn_like          # the input-noising draw of webcam mode uses the global generator (:657)
+        self.num_blocks = num_blocks if num_blocks is not None else noise.shape[1] // 3
         self.prompt_embeds = prompt_embeds          # list of [L_txt, text_dim]
         self.noise = noise                          # [1, num_blocks*3, 16, h, w]
         self.all_latents = torch.zeros_like(noise)
@@ -425,7 +434,7 @@ class SessionOracle:
         self.current_start_frame = 0
         self.scheduler = FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
         zp = torch.cat((self.scheduler.timesteps, torch.tensor([0], dtype=torch.float32)))
-        self.denoising_step_list = get_denoising_schedule(zp, 1.0, steps=num_steps)
+        self.denoising_step_list = get_denoising_schedule(zp, strength, steps=num_steps)
         n_heads, hd = cfg["num_heads"], cfg["dim"] // cfg["num_heads"]
         kv_size = (self.c + self.nfpb) * FRAME_SEQLEN   # init_models, release_server.py:543-549
         self.kv_cache = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype)
@@ -448,7 +457,11 @@ class SessionOracle:
         """release_server.py:588-633."""
         if self.block_idx == 0:
             reset_kv_cache(self.kv_cache)
-            return self.current_start_frame
+            if self.resume_latents is not None:     # :592-595: resume behind given latents (image-to-video start)
+                self.current_start_frame = self.resume_latents.shape[1]
+                self.all_latents[:, :self.current_start_frame] = self.resume_latents
+            else:
+                return self.current_start_frame
         start = min(self.current_start_frame, self.c)
         ctx = self.clean_context_frames()
         reset_kv_cache(self.kv_cache)
@@ -459,9 +472,25 @@ class SessionOracle:
 
     def generate_block(self):
         """generate_block_internal, release_server.py:636-708 (T2V branch), returns denoised latents."""
+        if self.block_idx >= self.num_blocks:
+            return None
         start = self.recompute_kv_cache()
-        noisy = self.noise[:, self.current_start_frame:self.current_start_frame + self.nfpb]
         steps = self.denoising_step_list
+        if self.webcam_encoder is not None:         # :651-657
+            latents = self.process_webcam_frames(self.block_idx)
+            if latents is None:
+                return None
+            s0 = steps[0] / 1000.0
+            latents = latents[None].to(self.noise.dtype).movedim(1, 2)
+            noisy = latents * (1.0 - s0) + self.randn_like(latents) * s0
+        else:
+            noisy = self.noise[:, self.current_start_frame:self.current_start_frame + self.nfpb]
+        if self.interpolated_prompt_embeds:         # :659-666: prompt transition -> fresh cross-attention K/V
+            for c in self.crossattn_cache:
+                c["k"].zero_()
+                c["v"].zero_()
+                c["is_init"] = False
+            self.prompt_embeds = [self.interpolated_prompt_embeds.pop(0)[0]]
         for index, current_timestep in enumerate(steps):
             timestep = torch.ones([1, self.nfpb], dtype=torch.int64) * current_timestep  # -> float32 (trap 4)
             _, denoised = wrapper_forward(self.w, self.cfg, self.scheduler, noisy, self.prompt_embeds, timestep,
@@ -477,7 +506,60 @@ class SessionOracle:
         self.all_latents[:, self.current_start_frame:self.current_start_frame + self.nfpb] = denoised
         self.current_start_frame += self.nfpb
         self.block_idx += 1
+        self.resume_latents = None
         return denoised
+
+    # ---- input side (the VAE encoder leg is a callable with VAEEncoderWrapper's contract)
+    def encode_video_latent(self, encoder, cache, frames, stream=False, max_frames=81):
+        """v2v.py:138-158 for in-memory frames [T, 3, H, W] at the target size (the bicubic resize is the identity there).
+        Returns (latents [16, T', h, w] fp16, cache)."""
+        if max_frames is None:
+            max_frames = 1 + ((frames.shape[0] - 1) // 4) * 4
+        frames = frames[:max_frames].transpose(0, 1).to(torch.float16)
+        lat, cache = encoder(frames.unsqueeze(0), cache, stream=stream)
+        return lat.squeeze(0).to(torch.float16), cache
+
+    def process_webcam_frames(self, idx):
+        """release_server.py:489-527: 9 (block 0) or 12 queued frames, resampled by index, encoded on the running cache."""
+        n = 9 if idx == 0 else 12
+        if len(self.frame_queue) < n:
+            return None
+        frames, self.frame_queue = self.frame_queue, []
+        lat, self.encode_vae_cache = self.encode_video_latent(self.webcam_encoder, self.encode_vae_cache,
+                                                              torch.stack(resample_array(frames, n)), stream=idx > 0)
+        return lat
+
+    def interpolate_prompt_embeds(self, new_embeds, interpolation_steps):
+        """release_server.py:459-468: lerp from the current to the new prompt embedding ([512, text_dim] each)."""
+        e1, e2 = self.prompt_embeds[0][None], new_embeds[None].to(torch.bfloat16)
+        x = torch.lerp(e1, e2, torch.linspace(0, 1, steps=interpolation_steps).unsqueeze(1).unsqueeze(2).to(e1))
+        self.interpolated_prompt_embeds = list(x.chunk(interpolation_steps, dim=0))
+
+    def setup_start_frame(self, image01, encoder):
+        """release_server.py:578-586: image [3, H, W] in [0, 1] repeated over the pixel context window -> resume_latents."""
+        n = 1 + (self.c - 1) * 4
+        tensor = image01.to(torch.float16).sub(0.5).mul(2.0)
+        lat, _ = self.encode_video_latent(encoder, [None] * 55, torch.stack([tensor] * n))
+        self.resume_latents = lat.transpose(0, 1)[None]
+
+    def setup_input_video(self, frames, encoder):
+        """release_server.py:417-428: offline v2v - the video's latents noised to the first step's level replace the noise and
+        bound the block count."""
+        s0 = self.denoising_step_list[0] / 1000
+        lat, _ = self.encode_video_latent(encoder, [None] * 55, frames, max_frames=None)
+        lat = lat[None].to(self.noise.dtype).movedim(1, 2)
+        eps = torch.randn(lat.shape, generator=self.rnd, dtype=self.noise.dtype)
+        self.noise = (lat * (1.0 - s0) + eps * s0).contiguous()
+        self.num_blocks = min(lat.shape[1] // self.nfpb - 1, self.num_blocks)
+
+
+def resample_array(array, target_length):
+    """release_server.py:57-62: index resampling of a list by rounded linspace."""
+    import numpy as np
+    if len(array) == target_length:
+        return array
+    idx = np.round(np.linspace(0, len(array) - 1, target_length)).astype(int)
+    return [array[i] for i in idx]
 
 
 # ------------------------------------------------------------------------------------------------

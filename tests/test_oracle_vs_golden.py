@@ -241,3 +241,77 @@ def test_session_oracle_matches_reference_generation_session(golden):
     assert len(enc_inputs) == len(gold["encoder_inputs"]) == 1                        # only block 2 re-encodes
     assert tuple(enc_inputs[0].unsqueeze(0).shape) == gold["encoder_input_shapes"][0]
     assert max_abs(enc_inputs[0].unsqueeze(0).float()[..., ::40, ::52], gold["encoder_inputs"][0]) <= 2e-2
+
+
+def _run_oracle_blocks(ora, gold, n, decode=True, tol=1e-2):
+    from collections import deque
+    from oracle import standins
+    frames_cache, vae_cache = deque(maxlen=9), [None] * 55
+    ora.first_frame_fn = lambda b: _session_harness_first_frame(frames_cache)[0]
+    for b in range(n):
+        yield b
+        out = ora.generate_block()
+        assert out is not None and rel_l2(out, gold["blocks"][b]) <= tol, b
+        px, vae_cache = standins.standin_decoder(out.half(), *vae_cache)
+        frames_cache.extend(px.split(1, dim=1))
+        assert (int(ora.kv_cache[0]["global_end_index"]), int(ora.kv_cache[0]["local_end_index"]),
+                ora.current_start_frame, ora.block_idx) == gold["indices"][b][:4]
+
+
+def test_session_oracle_webcam_mode_matches_reference_session(golden):
+    """Streaming v2v + prompt transition of SessionOracle vs the golden of the reference's GenerationSession in webcam mode."""
+    from oracle import standins
+    from oracle.make_golden import webcam_frames
+    gold = golden("session_webcam_reference.pt")
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    rnd = torch.Generator().manual_seed(9)
+    noise = torch.randn([1, 9, 16, 60, 104], dtype=torch.bfloat16, generator=rnd)
+    ora = wo.SessionOracle(w, cfg, [gold["prompts"][0][0]], noise, kv_cache_num_frames=3, num_steps=4, strength=0.8,
+                           webcam_encoder=standins.standin_encoder)
+    ora.rnd = rnd
+    assert torch.allclose(ora.denoising_step_list, gold["steps"])
+    frames = webcam_frames()
+    for b in _run_oracle_blocks(ora, gold, 3):
+        ora.frame_queue.extend(frames[b])
+        torch.manual_seed(100 + b)                       # the golden script seeds the global generator per block
+        if b == 1:
+            ora.interpolate_prompt_embeds(gold["prompts"][1][0], 2)
+    assert rel_l2(ora.all_latents, gold["all_latents"]) <= 1e-2
+    assert torch.equal(ora.prompt_embeds[0][None], gold["prompt_used"][2])
+
+
+def test_session_oracle_start_frame_matches_reference_session(golden):
+    import numpy as np
+    from oracle import standins
+    from oracle.make_golden import start_image
+    gold = golden("session_start_frame_reference.pt")
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    rnd = torch.Generator().manual_seed(9)
+    noise = torch.randn([1, 9, 16, 60, 104], dtype=torch.bfloat16, generator=rnd)
+    ora = wo.SessionOracle(w, cfg, [gold["prompt"][0]], noise, kv_cache_num_frames=3, num_steps=4)
+    ora.rnd = rnd
+    img = torch.from_numpy(np.asarray(start_image()).copy()).permute(2, 0, 1).float().div(255)
+    ora.setup_start_frame(img, standins.standin_encoder)
+    assert torch.allclose(ora.resume_latents.float(), gold["resume_latents"].float(), atol=2e-3)
+    for _ in _run_oracle_blocks(ora, gold, 2):
+        pass
+    assert rel_l2(ora.all_latents, gold["all_latents"]) <= 1e-2
+
+
+def test_session_oracle_offline_v2v_matches_reference_session(golden):
+    from oracle import standins
+    from oracle.make_golden import v2v_video
+    gold = golden("session_v2v_reference.pt")
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    rnd = torch.Generator().manual_seed(9)
+    noise = torch.randn([1, 15, 16, 60, 104], dtype=torch.bfloat16, generator=rnd)
+    ora = wo.SessionOracle(w, cfg, [gold["prompt"][0]], noise, kv_cache_num_frames=3, num_steps=4, strength=0.6, num_blocks=5)
+    ora.rnd = rnd
+    ora.setup_input_video(v2v_video(), standins.standin_encoder)
+    assert ora.num_blocks == gold["num_blocks"] and torch.equal(ora.noise, gold["noise"])
+    for _ in _run_oracle_blocks(ora, gold, 2):
+        pass
+    assert ora.generate_block() is None
