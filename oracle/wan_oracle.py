@@ -553,6 +553,58 @@ class SessionOracle:
         self.num_blocks = min(lat.shape[1] // self.nfpb - 1, self.num_blocks)
 
 
+def pipeline_inference(w, cfg, prompt_embeds, noise, initial_latent=None, denoising_step_list=(1000, 750, 500, 250),
+                       warp_denoising_step=False, independent_first_frame=False, context_noise=0, shift=5.0, kv_size=32760,
+                       randn_like=torch.randn_like, attn_fn=None):
+    """CausalInferencePipeline.inference, pipeline/causal_inference.py:48-277 (DiT part; Step 4's VAE decode is separate):
+    Step 2 caches the input frames at t = 0, Step 3 runs per block the denoising steps with re-noising between them and one
+    forward at `context_noise` that writes the clean K/V.  Returns (latents [1, F_in + F, 16, h, w], kv_cache)."""
+    nfpb = cfg.get("num_frame_per_block", 3)
+    scheduler = FlowMatchScheduler(shift=shift, sigma_min=0.0, extra_one_step=True)
+    steps = torch.tensor(list(denoising_step_list), dtype=torch.long)
+    if warp_denoising_step:                                                    # :29-32
+        steps = torch.cat((scheduler.timesteps, torch.tensor([0], dtype=torch.float32)))[1000 - steps]
+    n_heads, hd = cfg["num_heads"], cfg["dim"] // cfg["num_heads"]
+    kv = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype)
+    ca = initialize_crossattn_cache(cfg["num_layers"], 1, n_heads, hd, noise.dtype, cfg.get("text_len", 512))
+    num_frames = noise.shape[1]
+    n_in = initial_latent.shape[1] if initial_latent is not None else 0
+    if not independent_first_frame or initial_latent is not None:
+        num_blocks = num_frames // nfpb
+    else:
+        num_blocks = (num_frames - 1) // nfpb
+    output = torch.zeros([1, num_frames + n_in] + list(noise.shape[2:]), dtype=noise.dtype)
+    start = 0
+
+    def fwd(x, t):
+        return wrapper_forward(w, cfg, scheduler, x, prompt_embeds, t, kv, ca, start * FRAME_SEQLEN, attn_fn=attn_fn)
+
+    if initial_latent is not None:                                             # Step 2, :136-168
+        chunks = [1] if independent_first_frame else []
+        chunks += [nfpb] * ((n_in - len(chunks)) // nfpb)
+        for n in chunks:
+            ref = initial_latent[:, start:start + n]
+            output[:, start:start + n] = ref
+            fwd(ref, torch.zeros([1, n], dtype=torch.int64))
+            start += n
+    all_num_frames = [nfpb] * num_blocks
+    if independent_first_frame and initial_latent is None:
+        all_num_frames = [1] + all_num_frames
+    for cur in all_num_frames:                                                 # Step 3, :176-246
+        noisy = noise[:, start - n_in:start + cur - n_in]
+        for index, t_cur in enumerate(steps):
+            timestep = torch.ones([1, cur], dtype=torch.int64) * t_cur
+            _, denoised = fwd(noisy, timestep)
+            if index < len(steps) - 1:
+                flat = denoised.flatten(0, 1)
+                noisy = scheduler.add_noise(flat, randn_like(flat), steps[index + 1] * torch.ones([cur], dtype=torch.long)) \
+                    .unflatten(0, denoised.shape[:2])
+        output[:, start:start + cur] = denoised
+        fwd(denoised, torch.ones_like(timestep) * context_noise)
+        start += cur
+    return output, kv
+
+
 def resample_array(array, target_length):
     """release_server.py:57-62: index resampling of a list by rounded linspace."""
     import numpy as np

@@ -315,3 +315,20 @@ def test_session_oracle_offline_v2v_matches_reference_session(golden):
     for _ in _run_oracle_blocks(ora, gold, 2):
         pass
     assert ora.generate_block() is None
+
+
+def test_pipeline_inference_oracle_matches_reference_pipeline(golden):
+    """wo.pipeline_inference (restatement of CausalInferencePipeline.inference) vs the goldens of the reference's own class:
+    video extension, and the independent-first-frame [1, 3] structure with / without an image latent."""
+    top = golden("pipeline_inference_reference.pt")
+    cfg = dict(TINY)
+    w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
+    for variant in ("extension", "t2v_independent", "i2v_independent"):
+        gold = top if variant == "extension" else top[variant]
+        torch.manual_seed(gold.get("seed", 77))          # re-noising = torch.randn_like on the global generator
+        lat, kv = wo.pipeline_inference(w, cfg, [top["prompt"][0]], gold["noise"], gold["initial"], warp_denoising_step=True,
+                                        independent_first_frame=variant != "extension")
+        assert rel_l2(lat, gold["latents"]) <= 1e-2, variant
+        assert (int(kv[0]["global_end_index"]), int(kv[0]["local_end_index"])) == gold["indices"], variant
+        for c, g in zip(cache_sample(kv), gold["cache"]):
+            assert rel_l2(c["k"], g["k"]) <= 1e-2 and rel_l2(c["v"], g["v"]) <= 1e-2
