@@ -148,6 +148,8 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
       return launch_gemm9(p, f16, true, 2, stream);   //                       2 slabs
     case 52:
       return launch_gemm8(p, f16, 9, stream);      // A/B: as 50 with the phase barrier BEFORE the lgkmcnt(0) (no difference)
+    case 53:
+      return launch_gemm8(p, f16, 17, stream);     // A/B: as 50 with the K-tile bounds checks inside the steady-state loop
     case 50:
       return launch_gemm8(p, f16, 1, stream);      // = the default for large problems: DMA between MFMAs + split-K
     case 51:

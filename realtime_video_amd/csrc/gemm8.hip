@@ -23,6 +23,8 @@
 // of the tiles of the last, partial round over S workgroups; partial accumulators go through an fp32 slab
 // in a caller-provided workspace and the last arriver (agent-scope release / acquire + arrival counter)
 // sums them and runs the epilogue.
+#include <type_traits>
+
 #include "gemm_core.h"
 #include "gemm_split.h"
 #include "rtv_internal.h"
@@ -42,7 +44,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 
 }  // namespace g8
 
-template <bool F16, int NL, bool SYNC_FIRST = false>
+template <bool F16, int NL, bool SYNC_FIRST = false, bool PEEL = true>
 __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
   typedef TileCfg<256, 256, 64, 2, 4> Cfg;  // epilogue geometry: 4 x 2 blocks of 32x32 per wave
@@ -88,14 +90,16 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
       }
     }
   }
-  auto stage_piece = [&](int kt, int h, int j) {  // kt: K-tile, h: 0..3 = A0, A1, W0, W1, j: piece
-    if (kt >= kt_end) return;
+  // `chk` (std::true_type / false_type): whether the K-tile index still has to be compared with kt_end.  The steady-state
+  // iterations (kt + 2 < kt_end) stage unconditionally - no scalar compare + branch around every DMA piece inside the loop.
+  auto stage_piece = [&](int kt, int h, int j, auto chk) {  // kt: K-tile, h: 0..3 = A0, A1, W0, W1, j: piece
+    if (decltype(chk)::value && kt >= kt_end) return;
     const uint16_t* base = (h < 2 ? p.A : p.W) + (size_t)kt * BK;
     dma16(base + src_off[h][j], smem + slot_off(kt & 1, h) + (j * 64 + wave * 8) * 128);
   };
   auto stage_half = [&](int kt, int h) {
-    stage_piece(kt, h, 0);
-    stage_piece(kt, h, 1);
+    stage_piece(kt, h, 0, std::true_type{});
+    stage_piece(kt, h, 1, std::true_type{});
   };
 
   // ---- fragment addressing: A rows of this wave live in half-tile `wr`, W rows in half-tile 2 + (wc >> 1)
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   } while (0)
 
   // MFMA segment of one phase: 8 MFMA on one 64x32 quadrant (+ the DMA pieces not issued in the LDS segment)
-  auto mma_quadrant = [&](int mq, int nq, int st_kt, int st_h) {
+  auto mma_quadrant = [&](int mq, int nq, int st_kt, int st_h, auto chk) {
     __builtin_amdgcn_s_setprio(1);
     int n = 0;
 #pragma unroll
@@ -175,17 +179,17 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
         ++n;
         if ((NL == 0 && n == 2) || (NL <= 1 && n == 5)) {
           G8_FENCE();
-          stage_piece(st_kt, st_h, n == 2 ? 0 : 1);
+          stage_piece(st_kt, st_h, n == 2 ? 0 : 1, chk);
           G8_FENCE();
         }
       }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto stage_lds_seg = [&](int st_kt, int st_h) {  // the NL pieces issued in the LDS segment (after the reads)
+  auto stage_lds_seg = [&](int st_kt, int st_h, auto chk) {  // the NL pieces issued in the LDS segment (after the reads)
     if (NL >= 1) {
       G8_FENCE();
-      stage_piece(st_kt, st_h, NL == 2 ? 0 : 0);
-      if (NL == 2) stage_piece(st_kt, st_h, 1);
+      stage_piece(st_kt, st_h, NL == 2 ? 0 : 0, chk);
+      if (NL == 2) stage_piece(st_kt, st_h, 1, chk);
       G8_FENCE();
     }
   };
@@ -214,39 +218,44 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                       \
   } while (0)
 
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  auto k_tile = [&](const int kt, auto chk) {
+    constexpr bool CHK = decltype(chk)::value;
     const int buf = kt & 1;
     // ---------------- phase 1: quadrant (m0, n0), stages A0(kt+1)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bfr[0][ks] = bnext[ks];
     read_a(buf, 0);
-    stage_lds_seg(kt + 1, 0);
+    stage_lds_seg(kt + 1, 0, chk);
     G8_PHASE_SYNC();
-    mma_quadrant(0, 0, kt + 1, 0);
+    mma_quadrant(0, 0, kt + 1, 0, chk);
     G8_BARRIER();
     // ---------------- phase 2: quadrant (m0, n1), stages A1(kt+1); retire W0/W1(kt+1): phase 4 prefetches W[n0] of
     //                  K-tile kt+1 from them.  In flight afterwards: A0(kt+1) and the LDS-segment pieces of A1(kt+1).
     read_w(buf, 1, bfr[1]);
-    stage_lds_seg(kt + 1, 1);
-    if (kt + 1 < kt_end) G8_WAIT_KEEP();
+    stage_lds_seg(kt + 1, 1, chk);
+    if (!CHK || kt + 1 < kt_end) G8_WAIT_KEEP();
     G8_PHASE_SYNC();
-    mma_quadrant(0, 1, kt + 1, 1);
+    mma_quadrant(0, 1, kt + 1, 1, chk);
     G8_BARRIER();
     // ---------------- phase 3: quadrant (m1, n1), stages W0(kt+2) (the W slots of this buffer are free now)
     read_a(buf, 1);
-    stage_lds_seg(kt + 2, 2);
+    stage_lds_seg(kt + 2, 2, chk);
     G8_PHASE_SYNC();
-    mma_quadrant(1, 1, kt + 2, 2);
+    mma_quadrant(1, 1, kt + 2, 2, chk);
     G8_BARRIER();
     // ---------------- phase 4: quadrant (m1, n0), stages W1(kt+2); retire A0/A1(kt+1).
-    if (kt + 1 < kt_end) read_w(buf ^ 1, 0, bnext);
-    stage_lds_seg(kt + 2, 3);
-    if (kt + 2 < kt_end) G8_WAIT_KEEP();
+    if (!CHK || kt + 1 < kt_end) read_w(buf ^ 1, 0, bnext);
+    stage_lds_seg(kt + 2, 3, chk);
+    if (!CHK || kt + 2 < kt_end) G8_WAIT_KEEP();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     G8_PHASE_SYNC();
-    mma_quadrant(1, 0, kt + 2, 3);
+    mma_quadrant(1, 0, kt + 2, 3, chk);
     G8_BARRIER();
-  }
+  };
+  int kt = kt_begin;
+  if constexpr (PEEL)   // (PEEL = false, A/B config 53: every iteration keeps the checks)
+    for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});   // steady state: tiles kt+1 and kt+2 exist
+  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});          // last two K-tiles
   if (wr == 0) G8_BARRIER();  // group 0 closes the stagger
 
   // ---- split-K fix-up: publish the partial tile, last arriver reduces (placement-independent agent-scope
@@ -317,11 +326,11 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
   return 0;
 }
 
-template <bool F16, int NL, bool SYNC_FIRST = false>
+template <bool F16, int NL, bool SYNC_FIRST = false, bool PEEL = true>
 static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   p.tiles_m = (p.M + g8::BM - 1) / g8::BM;
   p.tiles_n = (p.N + g8::BN - 1) / g8::BN;
-  auto kern = gemm8_kernel<F16, NL, SYNC_FIRST>;
+  auto kern = gemm8_kernel<F16, NL, SYNC_FIRST, PEEL>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES);
@@ -341,6 +350,7 @@ int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream)
   const bool split = variant & 1;
   const int nl = (variant >> 1) & 3;
   if (variant & 8) return launch_gemm8_t<false, 0, true>(p, split, stream);  // A/B: barrier before the lgkmcnt wait
+  if (variant & 16) return launch_gemm8_t<false, 0, false, false>(p, split, stream);  // A/B: bounds checks kept in the loop
   if (f16) return launch_gemm8_t<true, 2>(p, split, stream);
   if (nl == 0) return launch_gemm8_t<false, 0>(p, split, stream);
   if (nl == 1) return launch_gemm8_t<false, 1>(p, split, stream);
