@@ -14,6 +14,8 @@
 // while each phase issues 4 v_mfma_f32_32x32x64_f8f6f4 (64 cycles, 4x the FLOPs of a 32x32x16 bf16 MFMA) instead of
 // 8 bf16 MFMAs: same time per K-tile, twice the work.  Fragment layout (scripts/micro/fp8_mfma.hip): lane l holds row
 // l & 31 and the 32 consecutive K bytes 32 * (l >> 5) .. +32 of a 64-deep step = two 16-byte LDS chunks.
+#include <type_traits>
+
 #include "gemm_core.h"
 #include "gemm_split.h"
 #include "rtv_internal.h"
@@ -94,14 +96,15 @@ __global__ __launch_bounds__(gf8::THREADS, 2) void gemm_fp8_kernel(GemmParams p,
       }
     }
   }
-  auto stage_piece = [&](int kt, int h, int j) {
-    if (kt >= kt_end) return;
+  // chk: std::true_type only in the last two K-tiles (gemm8.hip: the steady-state loop stages without bounds checks)
+  auto stage_piece = [&](int kt, int h, int j, auto chk) {
+    if (decltype(chk)::value && kt >= kt_end) return;
     const uint8_t* base = (h < 2 ? f.A : f.W) + (size_t)kt * BK;
     dma16(base + src_off[h][j], smem + slot_off(kt & 1, h) + (j * 64 + wave * 8) * 128);
   };
   auto stage_half = [&](int kt, int h) {
-    stage_piece(kt, h, 0);
-    stage_piece(kt, h, 1);
+    stage_piece(kt, h, 0, std::true_type{});
+    stage_piece(kt, h, 1, std::true_type{});
   };
 
   // ---- fragments:
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(gf8::THREADS, 2) void gemm_fp8_kernel(GemmParams p,
   } while (0)
 
   // MFMA segment of one phase: 4 MFMA 32x32x64 on one 64x32 quadrant, the phase's 2 DMA pieces between them
-  auto mma_quadrant = [&](int mq, int nq, int st_kt, int st_h) {
+  auto mma_quadrant = [&](int mq, int nq, int st_kt, int st_h, auto chk) {
     __builtin_amdgcn_s_setprio(1);
     int n = 0;
 #pragma unroll
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(gf8::THREADS, 2) void gemm_fp8_kernel(GemmParams p,
         ++n;
         if (n == 1 || n == 3) {
           GF_FENCE();
-          stage_piece(st_kt, st_h, n == 1 ? 0 : 1);
+          stage_piece(st_kt, st_h, n == 1 ? 0 : 1, chk);
           GF_FENCE();
         }
       }
@@ -182,30 +185,34 @@ __global__ __launch_bounds__(gf8::THREADS, 2) void gemm_fp8_kernel(GemmParams p,
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   GF_FENCE();
 
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
+  auto k_tile = [&](const int kt, auto chk) {
+    constexpr bool CHK = decltype(chk)::value;
     const int buf = kt & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) bfr[0][j] = bnext[j];
     read_a(buf, 0);
     GF_PHASE_SYNC();
-    mma_quadrant(0, 0, kt + 1, 0);
+    mma_quadrant(0, 0, kt + 1, 0, chk);
     GF_BARRIER();
     read_w(buf, 1, bfr[1]);
-    if (kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (!CHK || kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     GF_PHASE_SYNC();
-    mma_quadrant(0, 1, kt + 1, 1);
+    mma_quadrant(0, 1, kt + 1, 1, chk);
     GF_BARRIER();
     read_a(buf, 1);
     GF_PHASE_SYNC();
-    mma_quadrant(1, 1, kt + 2, 2);
+    mma_quadrant(1, 1, kt + 2, 2, chk);
     GF_BARRIER();
-    if (kt + 1 < kt_end) read_w(buf ^ 1, 0, bnext);
-    if (kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if (!CHK || kt + 1 < kt_end) read_w(buf ^ 1, 0, bnext);
+    if (!CHK || kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GF_PHASE_SYNC();
-    mma_quadrant(1, 0, kt + 2, 3);
+    mma_quadrant(1, 0, kt + 2, 3, chk);
     GF_BARRIER();
-  }
+  };
+  int kt = kt_begin;
+  for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});
+  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});
   if (wr == 0) GF_BARRIER();
 #undef GF_FENCE
 #undef GF_BARRIER
