@@ -231,3 +231,53 @@ def test_attention_plugin_installs_into_the_reference_modules():
         for m, s in zip(mods, saved):
             for n, v in s.items():
                 setattr(m, n, v)
+
+
+def test_cache_window_random_sequences_match_the_reference_rule():
+    """Property test of the KV bookkeeping (must match the reference EXACTLY): 150 random call sequences - window
+    sizes with and without attention sinks, 1- and 3-frame calls, repeated calls on the same block (denoising steps) - run
+    through CausalWanModel._cache_window on CPU cache tensors whose rows carry their write stamp, against the index
+    arithmetic and the eviction copy of causal_model.py:349-392 restated inline."""
+    import random
+    from realtime_video_amd.causal_model import CausalWanModel
+    rng = random.Random(7)
+    fs = 1560
+    for trial in range(150):
+        las = rng.choice([-1, 4, 6, 9])
+        sink = rng.choice([0, 1, 2]) if las != -1 else 0
+        kv_size = 32760 if las == -1 else las * fs
+        m = CausalWanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64, local_attn_size=las, sink_size=sink,
+                           device="cpu")
+        k = torch.zeros(1, kv_size, 1, 1)
+        kv = [{"k": k, "v": k.clone(), "global_end_index": 0, "local_end_index": 0}]
+        ref_k = torch.zeros(kv_size)                    # reference model of the cache: one stamp per row
+        g_end = l_end = 0
+        cur, stamp = 0, 0
+        for call in range(rng.randint(3, 14)):
+            num_new = fs * rng.choice([1, 3, 3])
+            if rng.random() < 0.4 and call > 0:
+                cur = prev_cur                            # another denoising step on the same block
+                num_new = prev_new
+            current_end = cur + num_new
+            max_att = 32760 if las == -1 else las * fs
+            sink_tokens = sink * fs
+            if las != -1 and current_end > g_end and num_new + l_end > kv_size:        # causal_model.py:363-379
+                evicted = num_new + l_end - kv_size
+                rolled = l_end - evicted - sink_tokens
+                ref_k[sink_tokens:sink_tokens + rolled] = ref_k[sink_tokens + evicted:sink_tokens + evicted + rolled].clone()
+                local_end = l_end + current_end - g_end - evicted
+            else:
+                local_end = l_end + current_end - g_end                                # :380-381
+            local_start = local_end - num_new
+            if local_start < 0 or local_end > kv_size:
+                break                                       # the reference would index out of range here; skip the tail
+            row0, lo, hi, start_frame, cb = m._cache_window(kv, num_new, cur, fs)
+            stamp += 1
+            kv[0]["k"][0, row0:row0 + num_new] = stamp    # what the forward's cache write does
+            ref_k[local_start:local_end] = stamp
+            g_end, l_end = current_end, local_end
+            assert (row0, lo, hi, start_frame, cb) == (local_start, max(0, local_end - max_att), local_end, cur // fs, 0), trial
+            assert (kv[0]["global_end_index"], kv[0]["local_end_index"]) == (g_end, l_end), trial
+            assert torch.equal(kv[0]["k"][0, :, 0, 0], ref_k), trial
+            prev_cur, prev_new = cur, num_new
+            cur = current_end
