@@ -281,3 +281,51 @@ def test_cache_window_random_sequences_match_the_reference_rule():
             assert torch.equal(kv[0]["k"][0, :, 0, 0], ref_k), trial
             prev_cur, prev_new = cur, num_new
             cur = current_end
+
+
+def test_cache_window_matches_the_real_reference_model_on_random_sequences():
+    """The same property against the REAL reference (authoring container only): the reference's CausalWanModel (1 layer, tiny
+    dims) is driven through random call sequences with local attention windows and sinks; after every call its cache
+    indices must equal those of CausalWanModel._cache_window fed the same sequence, and the set of cache rows it left
+    non-zero must be the window our bookkeeping reports."""
+    import random
+    import pytest
+    from oracle import ref_shim
+    if not ref_shim.available():
+        pytest.skip("reference tree not present")
+    from oracle import wan_oracle as wo
+    from oracle.make_golden import TEXT_DIM, TINY
+    from realtime_video_amd.causal_model import CausalWanModel
+    ref = ref_shim.load()
+    rng = random.Random(11)
+    fs = 1560
+    g = torch.Generator().manual_seed(2)
+    ctx = torch.randn(64, TEXT_DIM, generator=g).to(torch.bfloat16)
+    for trial, (las, sink) in enumerate([(4, 0), (6, 1), (6, 2), (9, 1)]):
+        cfg = dict(TINY, num_layers=1, local_attn_size=las, sink_size=sink)
+        w = wo.make_weights(cfg, seed=trial, text_dim=TEXT_DIM)
+        rmodel = ref_shim.build_reference_model(ref, cfg, w, TEXT_DIM)
+        wr = ref_shim.build_reference_wrapper(ref, rmodel)
+        kv_size = las * fs
+        rkv = [{"k": torch.zeros(1, kv_size, 2, 128, dtype=torch.bfloat16), "v": torch.zeros(1, kv_size, 2, 128, dtype=torch.bfloat16),
+                "global_end_index": torch.tensor([0]), "local_end_index": torch.tensor([0])}]
+        rca = [{"k": torch.zeros(1, 512, 2, 128, dtype=torch.bfloat16), "v": torch.zeros(1, 512, 2, 128, dtype=torch.bfloat16),
+                "is_init": False}]
+        ours = CausalWanModel(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=2, num_layers=1, text_dim=TEXT_DIM,
+                              local_attn_size=las, sink_size=sink, device="cpu")
+        okv = [{"k": torch.zeros(1, kv_size, 1, 1), "v": torch.zeros(1, kv_size, 1, 1), "global_end_index": 0, "local_end_index": 0}]
+        cur = 0
+        for call in range(7):
+            frames = rng.choice([1, 3])
+            if call and rng.random() < 0.35:
+                cur, frames = prev
+            lat = torch.randn(1, frames, 16, 60, 104, generator=g).to(torch.bfloat16)
+            with torch.inference_mode():
+                wr(lat, {"prompt_embeds": [ctx]}, torch.ones([1, frames], dtype=torch.int64) * 500, rkv, rca, current_start=cur)
+            row0, lo, hi, sf, cb = ours._cache_window(okv, frames * fs, cur, fs)
+            assert (int(rkv[0]["global_end_index"]), int(rkv[0]["local_end_index"])) == \
+                (okv[0]["global_end_index"], okv[0]["local_end_index"]), (trial, call)
+            written = rkv[0]["k"][0].float().abs().sum((-1, -2)) > 0
+            assert bool(written[:hi].all()) and not bool(written[hi:].any()), (trial, call)     # rows [0, local_end) are live
+            prev = (cur, frames)
+            cur += frames * fs
