@@ -57,6 +57,19 @@ int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o,
                  int64_t v_batch_stride, int64_t v_row_stride,
                  int64_t o_batch_stride, int64_t o_row_stride,
                  float scale, int causal_block, int q_offset, int dtype, rtv_stream_t stream);
+
+/* The same over a key window made of TWO row ranges of the cache: keys [0, Lkv0) are rows 0.. of k / v, keys
+ * [Lkv0, Lkv0 + Lkv1) are rows seg1_row.. (relative to k / v, may be negative).  This is how the rolling KV cache of
+ * causal_model.py:363-379 is attended once it is kept as a ring instead of being shifted: the window [sink | ring] is at most
+ * two physical ranges, and softmax attention does not depend on the key order.  Lkv1 == 0 is rtv_attn_fwd; the block-causal
+ * mask needs Lkv1 == 0. */
+int rtv_attn_fwd_win(const void* q, const void* k, const void* v, void* o,
+                     int B, int Lq, int Lkv0, int Lkv1, int seg1_row, int H, int D,
+                     int64_t q_batch_stride, int64_t q_row_stride,
+                     int64_t k_batch_stride, int64_t k_row_stride,
+                     int64_t v_batch_stride, int64_t v_row_stride,
+                     int64_t o_batch_stride, int64_t o_row_stride,
+                     float scale, int causal_block, int q_offset, int dtype, rtv_stream_t stream);
 /* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
  * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  A tuning knob for A/B measurements. */
 int rtv_attn_set_waves(int waves);
@@ -77,12 +90,17 @@ int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
 
 /* tile_cfg: 0 = default (gemm8 + split-K when the problem fills the chip with 256x256 tiles, else 128x128);
  * 1 = 128x128 tiles (2 workgroups per CU); 2/3 = 256x128 / 256x256 simple double buffer;
- * 4 = 256x256 ping-pong pipeline (gemm8.hip); 5 = 4 + split-K of the last partial round of tiles (needs the
- * workspace below); 6 / 7 = 256x256 software-pipelined variant (gemm9.hip) without / with that split-K.  The split-K partial sums live in a caller-owned fp32 workspace: */
+ * 4 = 256x256 ping-pong pipeline (gemm8.hip); 5 = 4 + split-K of the last partial round of tiles (needs a
+ * workspace, below); 50..53 = A/B builds of 5 with one schedule detail changed (all compute the same result).
+ * The split-K partial sums live in a caller-owned fp32 workspace.  A workspace must not be used by two launches that can
+ * overlap in time, so it is attached per (device, stream): rtv_gemm_set_stream_workspace(stream, ...) for launches on that
+ * stream of the CURRENT device; rtv_gemm_set_workspace(...) attaches a device-wide default used by the streams that have none
+ * of their own (correct while one stream per device issues split-K GEMMs).  Without a workspace the GEMM runs unsplit. */
 size_t rtv_gemm_workspace_bytes(void);
 int rtv_gemm_set_workspace(void* ptr, size_t bytes);   /* ptr == NULL detaches it.  Zeroes the arrival counters with a
                                                           synchronous hipMemset (call it at set-up time, not under graph
                                                           capture); launches leave the counters at zero. */
+int rtv_gemm_set_stream_workspace(rtv_stream_t stream, void* ptr, size_t bytes);
 
 /* ---- K5: fused norm / modulation / RoPE / KV-cache write ----------------------------------
  * rtv_layernorm_modulate: out = LN(x; eps, no affine) * (1 + scale[f]) + shift[f], f = (row_offset + m) / rows_per_frame
@@ -110,6 +128,15 @@ int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_
                            int M, int d, int num_heads, float eps,
                            const void* wq, const void* wk, const void* rope_cs,
                            int F, int gh, int gw, int start_frame, int row_offset, rtv_stream_t stream);
+/* ... with the cache kept as a ring (replaces the eviction shift copy of causal_model.py:363-379): logical cache
+ * row r >= ring_lo is stored at ring_lo + (r - ring_lo + ring_shift) % ring_size; rows below ring_lo (attention sink) do not
+ * move.  ring_size == 0 is the plain call. */
+int rtv_qk_norm_rope_cache_ring(const void* qkv, void* q_out, void* k_cache, void* v_cache,
+                                int64_t cache_row_stride, int cache_row0,
+                                int M, int d, int num_heads, float eps,
+                                const void* wq, const void* wk, const void* rope_cs,
+                                int F, int gh, int gw, int start_frame, int row_offset,
+                                int ring_lo, int ring_size, int ring_shift, rtv_stream_t stream);
 
 /* rtv_modulation_table: emod[l][f][j][:] = bf16(modulation[l][j][:] + e0[f][j][:]) for l<L, j<J
  *   (causal_model.py:466, :521).  modulation:[L][J][d], e0:[F][J0][d] with J0 = J or 1 (broadcast). */
@@ -185,6 +212,8 @@ typedef struct rtv_dit_step {
   int causal_block;         /* 0 = dense; >0 = block-causal recompute pass (tokens per block, :305-348) */
   int gemm_tile_cfg;        /* 0 = default */
   int row_begin, row_count; /* token rows owned by this rank (context parallel); 0,0 = all M rows */
+  int ring_lo, ring_size, ring_shift; /* rolling cache kept as a ring: cache_row0 / kv_lo / kv_hi are LOGICAL rows; logical row
+                               r >= ring_lo lives at ring_lo + (r - ring_lo + ring_shift) % ring_size (ring_size 0: no ring) */
 } rtv_dit_step;
 
 size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw);

@@ -29,6 +29,9 @@ SIGNATURES = {
     "rtv_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
                      c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                      c_f32, c_int, c_int, c_int, c_vp],
+    "rtv_attn_fwd_win": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                         c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                         c_f32, c_int, c_int, c_int, c_vp],
     "rtv_attn_set_waves": [c_int],
     "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
                  c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
@@ -36,12 +39,15 @@ SIGNATURES = {
     "rtv_rmsnorm": [c_vp, c_int, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp],
     "rtv_qk_norm_rope_cache": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32,
                                c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_qk_norm_rope_cache_ring": [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_f32,
+                                    c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp],
     "rtv_modulation_table": [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp],
     "rtv_sinusoidal_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
     "rtv_patchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "rtv_unpatchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "rtv_pixels_to_rgb8": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "rtv_gemm_set_workspace": [c_vp, ctypes.c_size_t],
+    "rtv_gemm_set_stream_workspace": [c_vp, c_vp, ctypes.c_size_t],
     "rtv_probe_mfma": [c_vp, c_vp, c_vp, c_vp],
     "rtv_probe_tr": [c_vp, c_vp, c_int, c_int, c_vp],
 }

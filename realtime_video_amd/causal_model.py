@@ -59,7 +59,8 @@ class _Step(ctypes.Structure):
                 ("compute_cross_kv", ctypes.c_int), ("cache_row0", ctypes.c_int),
                 ("kv_lo", ctypes.c_int), ("kv_hi", ctypes.c_int), ("start_frame", ctypes.c_int),
                 ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int),
-                ("row_begin", ctypes.c_int), ("row_count", ctypes.c_int)]
+                ("row_begin", ctypes.c_int), ("row_count", ctypes.c_int),
+                ("ring_lo", ctypes.c_int), ("ring_size", ctypes.c_int), ("ring_shift", ctypes.c_int)]
 
 
 _lib.EXTRA_SIGNATURES["rtv_dit_forward"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step),
@@ -101,13 +102,25 @@ class _SelfAttnHandle:
         self.sink_size = sink_size
         self.num_frame_per_block = 1
         self.fused_projections = True  # q/k/v are always stored fused here
-
-    @property
-    def max_attention_size(self):
-        return 32760 if self.local_attn_size == -1 else self.local_attn_size * 1560
+        # fixed at construction like the reference (causal_model.py:192): later writes to local_attn_size
+        # (release_server.py:544-546 sets -1) do not change the attention window
+        self.max_attention_size = 32760 if local_attn_size == -1 else local_attn_size * 1560
 
     def fuse_projections(self):
         self.fused_projections = True
+
+
+def cache_row_map(cache, sink_tokens=None):
+    """Physical cache row of every LIVE logical row [0, local_end_index) of one kv_cache entry.  The rolling cache is kept as a
+    ring (no eviction copies): logical row r >= ring_lo lives at ring_lo + (r - ring_lo + ring_start) % ring_size.  For
+    inspection / tests: `cache["k"][:, cache_row_map(cache)]` is what the reference's shifted cache holds in rows
+    [0, local_end_index)."""
+    n = int(cache["local_end_index"])
+    r = torch.arange(n)
+    lo, size, start = (int(cache.get(k, 0)) for k in ("ring_lo", "ring_size", "ring_start"))
+    if size > 0:
+        r = torch.where(r >= lo, lo + (r - lo + start) % size, r)
+    return r
 
 
 class CausalWanModel:
@@ -137,6 +150,7 @@ class CausalWanModel:
         self._ws = {}           # (F, gh, gw) -> workspace tensor
         self.use_hip_graphs = False   # replay each distinct forward (recompute / denoise step) from a captured hipGraph
         self._graphs = {}
+        self._weights_version = 0     # part of the graph key: a captured graph embeds weight pointers and the launch sequence
         self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps, 0)
 
     # ------------------------------------------------------------------ nn.Module-ish conveniences
@@ -200,6 +214,8 @@ class CausalWanModel:
         w.layers = ctypes.cast(layers, ctypes.POINTER(_LayerW))
         self._layers_arr = layers
         self._tensors, self._w = t, w
+        self._graphs.clear()            # captured graphs point at the previous weights
+        self._weights_version += 1
         return [], []
 
     def enable_fp8(self):
@@ -236,6 +252,8 @@ class CausalWanModel:
         self._fp8_scales = scales
         self._w.fp8_scales = ctypes.cast(scales, ctypes.POINTER(ctypes.c_float))
         self._cfg.use_fp8 = 1
+        self._graphs.clear()              # captured graphs replay the bf16 launch sequence on freed bf16 weights
+        self._weights_version += 1
         self._ws.clear()                  # the workspace grows by the fp8 activation buffer
         ops.ensure_gemm_workspace(self.device)
         return self
@@ -318,40 +336,75 @@ class CausalWanModel:
             self._xbufs[key] = b
         return b
 
-    def _cache_window(self, kv_cache, num_new, current_start, frame_seqlen):
-        """Integer bookkeeping of CausalWanSelfAttention.forward (causal_model.py:305-314 and :349-392).
-        Returns (cache_row0, kv_lo, kv_hi, start_frame, causal_block) and updates every layer's indices;
-        performs the rolling eviction copy when the local window overflows (:363-379)."""
+    def _cache_window(self, kv_cache, num_new, current_start, frame_seqlen, ring=True):
+        """Integer bookkeeping of CausalWanSelfAttention.forward (causal_model.py:305-314 and :349-392).  Returns
+        `(cache_row0, kv_lo, kv_hi, start_frame, causal_block, (ring_lo, ring_size, ring_shift), commit)`: the LOGICAL rows
+        this call writes / attends - the numbers of the reference - plus the ring mapping, and `commit()`, which stores the new
+        indices in every layer's dict and must be called once the forward has been issued (a forward that raises leaves the
+        bookkeeping where it was).
+
+        Rolling eviction (:363-379): the reference shifts the non-sink rows down by `evicted` (a clone + copy of the whole
+        cache per layer).  Here the non-sink region is a ring: the eviction only advances `ring_start`, new rows land at
+        ring_lo + (r - ring_lo + ring_start) % ring_size and the attention kernel walks the (at most two) physical row
+        ranges of the window (rtv_attn_fwd_win) - zero copies.  `ring=False` (context-parallel exchanges, which move
+        contiguous row blocks) keeps the reference's shift copy."""
         c0 = kv_cache[0]
-        if self.block_mask is not None:  # KV-recompute pass over clean context frames
-            local_end = num_new
-            for c in kv_cache:
-                c["global_end_index"] = local_end
-                c["local_end_index"] = local_end
-            return 0, 0, local_end, 0, self.block_mask.block_tokens
+        kv_size = c0["k"].shape[1]
+        if self.block_mask is not None:  # KV-recompute pass over clean context frames: rows [0, num_new), unrotated
+            if num_new > kv_size:
+                raise RuntimeError(f"KV cache window [0, {num_new}) outside cache of {kv_size} rows")
+
+            def commit_rc():
+                for c in kv_cache:
+                    c["global_end_index"] = num_new
+                    c["local_end_index"] = num_new
+                    c["ring_lo"], c["ring_size"], c["ring_start"] = 0, 0, 0
+            return 0, 0, num_new, 0, self.block_mask.block_tokens, (0, 0, 0), commit_rc
         sa = self.blocks[0].self_attn
         g_end, l_end = int(c0["global_end_index"]), int(c0["local_end_index"])
         current_end = current_start + num_new
-        kv_size = c0["k"].shape[1]
         sink_tokens = sa.sink_size * frame_seqlen
+        ring_lo, ring_size = int(c0.get("ring_lo", 0)), int(c0.get("ring_size", 0))
+        ring_start = int(c0.get("ring_start", 0)) if l_end > 0 else 0      # a reset cache (indices 0) is unrotated
+        shift_copy = None
         if sa.local_attn_size != -1 and current_end > g_end and num_new + l_end > kv_size:
             evicted = num_new + l_end - kv_size
             rolled = l_end - evicted - sink_tokens
-            for c in kv_cache:  # K8: eviction as a shift copy, like the reference (ring indexing is future work)
-                for n in ("k", "v"):
-                    c[n][:, sink_tokens:sink_tokens + rolled] = \
-                        c[n][:, sink_tokens + evicted:sink_tokens + evicted + rolled].clone()
+            if ring and rolled <= 0:
+                # nothing behind the sink survives (the reference's copy is an empty slice): the new rows overwrite the whole
+                # non-sink region, so the rotation is irrelevant from here on
+                ring_start = 0
+            elif ring:
+                if ring_size == 0 or ring_start == 0:
+                    ring_lo, ring_size = sink_tokens, kv_size - sink_tokens
+                elif (ring_lo, ring_size) != (sink_tokens, kv_size - sink_tokens):
+                    raise RuntimeError("the attention sink changed under a rotated rolling cache")
+                ring_start = (ring_start + evicted) % ring_size
+            else:
+                shift_copy = (sink_tokens, evicted, rolled)
             local_end = l_end + current_end - g_end - evicted
         else:
             local_end = l_end + current_end - g_end
+        if not ring and ring_start:
+            raise RuntimeError("this KV cache is rotated (ring_start != 0): reset it before using it under context parallelism")
         local_start = local_end - num_new
         if local_start < 0 or local_end > kv_size:
             raise RuntimeError(f"KV cache window [{local_start}, {local_end}) outside cache of {kv_size} rows")
         lo = max(0, local_end - sa.max_attention_size)
-        for c in kv_cache:
-            c["global_end_index"] = current_end
-            c["local_end_index"] = local_end
-        return local_start, lo, local_end, current_start // frame_seqlen, 0
+        if ring_start == 0:
+            ring_lo = ring_size = 0         # unrotated: logical == physical
+
+        def commit():
+            if shift_copy is not None:      # causal_model.py:368-373
+                s0, ev, ro = shift_copy
+                for c in kv_cache:
+                    for n in ("k", "v"):
+                        c[n][:, s0:s0 + ro] = c[n][:, s0 + ev:s0 + ev + ro].clone()
+            for c in kv_cache:
+                c["global_end_index"] = current_end
+                c["local_end_index"] = local_end
+                c["ring_lo"], c["ring_size"], c["ring_start"] = ring_lo, ring_size, ring_start
+        return local_start, lo, local_end, current_start // frame_seqlen, 0, (ring_lo, ring_size, ring_start), commit
 
     def _forward_inference(self, x, t, context, seq_len=None, clip_fea=None, y=None, kv_cache=None,
                            crossattn_cache=None, current_start=0, cache_start=0):
@@ -384,7 +437,10 @@ class CausalWanModel:
             cu = context[0] if not torch.is_tensor(context) else context[0]
             ctx = torch.zeros(self.text_len, self.text_dim, dtype=torch.bfloat16, device=u.device)
             ctx[:cu.shape[0]] = cu.to(torch.bfloat16)
-        row0, lo, hi, start_frame, causal_block = self._cache_window(kv_cache, M, current_start, fs)
+        cp = self.context_parallel
+        use_cp = cp is not None and cp.world > 1
+        row0, lo, hi, start_frame, causal_block, (ring_lo, ring_size, ring_shift), commit = \
+            self._cache_window(kv_cache, M, current_start, fs, ring=not use_cp)
         L = self.num_layers
         rs = kv_cache[0]["k"].stride(1)
         for c in kv_cache:
@@ -402,7 +458,6 @@ class CausalWanModel:
         ck_keep, ck = ptr_array([c["k"] for c in crossattn_cache])
         cv_keep, cv = ptr_array([c["v"] for c in crossattn_cache])
         out = torch.empty((self.out_dim, F, Hh, Ww), dtype=torch.bfloat16, device=u.device)
-        cp = self.context_parallel
         stream = c_vp(torch.cuda.current_stream().cuda_stream)
         cfg_p, w_p = ctypes.byref(self._cfg), ctypes.byref(self._w)
 
@@ -411,41 +466,53 @@ class CausalWanModel:
             ws_ptr = (ws.data_ptr() + 255) & ~255
             st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
                        F, gh, gw, kk, kv, rs, ck, cv, int(need_cross), row0, lo, hi,
-                       start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1])
+                       start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1],
+                       ring_lo, ring_size, ring_shift)
             return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
 
         if self.gemm_tile_cfg in (0, 5):
             ops.ensure_gemm_workspace(u.device)
-        if cp is None or cp.world == 1:
+        if use_cp:
+            commit()          # the exchanges below address the (shifted) cache rows
+        if not use_cp:
             graph_key = None
             if self.use_hip_graphs and not need_cross:
                 # the ~530 launches of one forward replayed as ONE hipGraph.  Everything the launch sequence
                 # depends on is part of the key (steady state has two entries: the recompute pass and the denoise step);
                 # the latent / timestep / output live in static buffers.  The first sighting of a key runs eagerly.
-                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, int(self.gemm_tile_cfg), rs,
+                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, ring_lo, ring_size, ring_shift,
+                             int(self.gemm_tile_cfg), rs, self._weights_version,
                              kv_cache[0]["k"].data_ptr(), kv_cache[-1]["v"].data_ptr(), crossattn_cache[0]["k"].data_ptr())
                 ent = self._graphs.get(graph_key)
                 if isinstance(ent, dict):
                     ent["u"].copy_(u)
                     ent["t"].copy_(tt)
                     ent["graph"].replay()
+                    commit()
                     return ent["out"].clone().unsqueeze(0)
             if graph_key is not None and self._graphs.get(graph_key) == "seen":
                 ent = {"u": u.clone(), "t": tt.clone(), "out": out, "keep": (kk_keep, kv_keep, ck_keep, cv_keep)}
                 u, tt = ent["u"], ent["t"]
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                if not hasattr(self, "_capture_stream"):
+                    self._capture_stream = torch.cuda.Stream(device=u.device)
+                # split-K workspaces are per (device, stream): attach one for the capture stream BEFORE capture begins
+                # (attaching allocates and memsets); the captured launches keep using it on whichever stream replays them
+                ops.ensure_gemm_workspace(u.device, self._capture_stream.cuda_stream)
+                with torch.cuda.graph(g, stream=self._capture_stream):
                     stream = c_vp(torch.cuda.current_stream().cuda_stream)
                     st, wsa = make((0, 0), 0)
                     _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)
                 ent["graph"], ent["step"] = g, st
                 self._graphs[graph_key] = ent
                 g.replay()
+                commit()
                 return out.clone().unsqueeze(0)
             if graph_key is not None:
                 self._graphs[graph_key] = "seen"
             st, wsa = make((0, 0), 0)
             _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)
+            commit()
         else:
             # context parallel: local rows only, ONE K/V all-gather per layer (parallel.py).  `local_ranks` is
             # [rank] in production; a single-process simulation of several ranks runs them in lockstep.

@@ -32,6 +32,9 @@ struct AttnParams {
   float scale_log2e;
   int causal_block, q_offset;
   int n_qtiles;
+  // two-segment key window (ring-indexed rolling KV cache, causal_model.py:363-379 without the shift copy): key v of the
+  // window is cache row v for v < n0 and row v + delta for v >= n0 (rows relative to k / v); n0 == Lkv: one segment.
+  int n0, delta;
 };
 
 constexpr int ATT_D = 128;
@@ -140,9 +143,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
   const uint32_t v_goff = (uint32_t)(st_r * (int)p.v_rs + st_c * 8) * 2u;
   auto load_tile = [&](int j) {
     const int row0 = j * ATT_KT;
-    if (row0 + ATT_KT <= p.Lkv) {
-      const char* kj = (const char*)(kb + (size_t)row0 * p.k_rs);
-      const char* vj = (const char*)(vb + (size_t)row0 * p.v_rs);
+    const bool in0 = row0 + ATT_KT <= p.n0;
+    if (in0 || (row0 >= p.n0 && row0 + ATT_KT <= p.Lkv)) {
+      const int64_t prow = in0 ? row0 : row0 + p.delta;
+      const char* kj = (const char*)(kb + prow * p.k_rs);
+      const char* vj = (const char*)(vb + prow * p.v_rs);
 #pragma unroll
       for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
         kreg[i] = *(const u32x4*)(kj + (size_t)(i * ATT_RSTEP) * p.k_rs * 2 + k_goff);
@@ -152,8 +157,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < ATT_LD_PER_THREAD; ++i) {
         int kv = min(row0 + st_r + i * ATT_RSTEP, p.Lkv - 1);
-        kreg[i] = *(const u32x4*)(kb + (size_t)kv * p.k_rs + st_c * 8);
-        vreg[i] = *(const u32x4*)(vb + (size_t)kv * p.v_rs + st_c * 8);
+        if (kv >= p.n0) kv += p.delta;
+        kreg[i] = *(const u32x4*)(kb + (int64_t)kv * p.k_rs + st_c * 8);
+        vreg[i] = *(const u32x4*)(vb + (int64_t)kv * p.v_rs + st_c * 8);
       }
     }
   };
@@ -326,6 +332,19 @@ extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o
                             int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
                             int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
                             int causal_block, int q_offset, int dtype, rtv_stream_t stream) {
+  return rtv_attn_fwd_win(q, k, v, o, B, Lq, Lkv, 0, 0, H, D, q_batch_stride, q_row_stride, k_batch_stride, k_row_stride,
+                          v_batch_stride, v_row_stride, o_batch_stride, o_row_stride, scale, causal_block, q_offset, dtype,
+                          stream);
+}
+
+extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
+                                int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
+                                int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
+                                int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
+                                int causal_block, int q_offset, int dtype, rtv_stream_t stream) {
+  if (Lkv0 < 0 || Lkv1 < 0) return set_error(-1, "attn_fwd: negative segment length");
+  if (Lkv1 > 0 && causal_block > 0) return set_error(-1, "attn_fwd: the block-causal mask needs a one-segment window");
+  const int Lkv = Lkv0 + Lkv1;
   if (D != ATT_D) return set_error(-1, "attn_fwd: head_dim must be 128");
   if (B <= 0 || H <= 0 || Lq <= 0) return 0;
   if (Lkv <= 0) return set_error(-1, "attn_fwd: Lkv must be positive");
@@ -356,6 +375,8 @@ extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o
   p.scale_log2e = scale * 1.4426950408889634f;
   p.causal_block = causal_block;
   p.q_offset = q_offset;
+  p.n0 = Lkv1 > 0 ? Lkv0 : Lkv;
+  p.delta = Lkv1 > 0 ? seg1_row - Lkv0 : 0;
   // 256-row workgroups unless their grid leaves most CUs idle: then 128-row ones.  Measured (MI355X, Lkv 14040, ms for 8 / 4
   // waves): 4680 rows x 20 heads 0.90 / 0.88, x 10 heads (190 workgroups) 0.46 / 0.51, x 5 heads (95) 0.40 / 0.32,
   // 585 rows x 40 heads (120) 0.40 / 0.34.

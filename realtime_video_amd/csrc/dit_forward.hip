@@ -113,6 +113,11 @@ static int make_ctx(const rtv_dit_config* cfg, const rtv_dit_weights* w, const r
   if (st->kv_lo < 0 || st->kv_hi <= st->kv_lo) return set_error(-1, "dit: empty attention window");
   if (st->cache_row0 < 0 || st->cache_row0 + c->M > st->kv_hi)
     return set_error(-1, "dit: the rows written by this call must lie inside the attention window");
+  if (st->ring_size < 0 || st->ring_lo < 0 || st->ring_shift < 0 || (st->ring_size > 0 && st->ring_shift >= st->ring_size) ||
+      (st->ring_size > 0 && st->kv_hi > st->ring_lo + st->ring_size))
+    return set_error(-1, "dit: bad ring window (0 <= ring_shift < ring_size, kv_hi <= ring_lo + ring_size)");
+  if (st->ring_size > 0 && st->ring_shift > 0 && st->causal_block > 0)
+    return set_error(-1, "dit: the block-causal recompute pass writes an unrotated cache (ring_shift must be 0)");
   if (((uintptr_t)workspace) & 255) return set_error(-1, "dit: workspace must be 256-byte aligned");
   bool ok = true;
   carve(cfg, c->F, c->gh, c->gw, (char*)workspace, workspace_bytes, &c->b, &ok);
@@ -206,13 +211,35 @@ static int dit_layer_qkv(Ctx& c, int l) {
   const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;  // [F][6][d]: shift_sa, scale_sa, gate_sa, shift_ffn, scale_ffn, gate_ffn
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_QKV, b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
-  RTV_TRY(rtv_qk_norm_rope_cache(b.qkv, b.q, st->kv_k[l], st->kv_v[l], st->kv_row_stride, st->cache_row0, c.rc, d, c.H,
-                                 c.cfg->eps, lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame,
-                                 c.r0, c.stream));
+  RTV_TRY(rtv_qk_norm_rope_cache_ring(b.qkv, b.q, st->kv_k[l], st->kv_v[l], st->kv_row_stride, st->cache_row0, c.rc, d, c.H,
+                                      c.cfg->eps, lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame,
+                                      c.r0, st->ring_lo, st->ring_size, st->ring_shift, c.stream));
   return 0;
 }
 
 static int dit_after_attn(Ctx& c, int l);
+
+// Physical row ranges of the logical attention window [kv_lo, kv_hi) of a ring-indexed cache: at most two, because the
+// sink rows [.., ring_lo) are adjacent to the ring's first physical row and the ring part wraps at most once.
+struct KeyWindow {
+  int row0, n0, row1, n1;
+};
+static KeyWindow key_window(const rtv_dit_step* st) {
+  const int lo = st->kv_lo, hi = st->kv_hi, S = st->ring_lo, R = st->ring_size;
+  if (R <= 0 || hi <= S) return KeyWindow{lo, hi - lo, 0, 0};
+  const int rl = lo > S ? lo : S;                       // logical start of the ring part
+  const int n = hi - rl;                                // ring rows in the window
+  const int p0 = S + (rl - S + st->ring_shift) % R;     // its first physical row
+  const int first = (p0 + n <= S + R) ? n : S + R - p0; // rows before the wrap
+  const int sink = lo < S ? S - lo : 0;
+  if (first == n) {                                     // no wrap: [lo, S) then [p0, p0 + n)
+    if (sink == 0) return KeyWindow{p0, n, 0, 0};
+    if (p0 == S) return KeyWindow{lo, sink + n, 0, 0};
+    return KeyWindow{lo, sink, p0, n};
+  }
+  // wrapped: [p0, S + R) and [S, S + n - first); the sink rows are adjacent to the second piece
+  return KeyWindow{sink ? lo : S, sink + n - first, p0, first};
+}
 
 // ---- layer, part 2: attention over the cache window -> o-proj(+gate,+res) -> cross-attn -> FFN
 static int dit_layer_rest(Ctx& c, int l) {
@@ -227,9 +254,11 @@ static int dit_layer_rest(Ctx& c, int l) {
   uint16_t* kc = (uint16_t*)st->kv_k[l];
   uint16_t* vc = (uint16_t*)st->kv_v[l];
   // self attention (causal_model.py:386-390, :470-476)
-  RTV_TRY(rtv_attn_fwd(b.q, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, b.ao, 1, rc, Lkv, H, hd,
-                       0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block, st->causal_block > 0 ? q_offset : 0,
-                       RTV_DTYPE_BF16, stream));
+  KeyWindow kw = key_window(st);
+  RTV_TRY(rtv_attn_fwd_win(b.q, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, b.ao, 1, rc, kw.n0, kw.n1,
+                           kw.row1 - kw.row0, H, hd, 0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block,
+                           st->causal_block > 0 ? q_offset : 0, RTV_DTYPE_BF16, stream));
+  (void)Lkv;
   return dit_after_attn(c, l);
 }
 
@@ -281,7 +310,7 @@ static int dit_layer_qkv_hp(Ctx& c, int l, int world, void* q_send, void* kv_sen
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_QKV, b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
   return qk_norm_rope_launch(b.qkv, q_send, kv_send, (uint16_t*)kv_send + gc, 2 * gc, 0, c.rc, d, c.H, c.cfg->eps, lw.norm_q_w,
                              lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, c.st->start_frame, c.r0, gc, (int64_t)c.rc * gc,
-                             (int64_t)c.rc * 2 * gc, c.stream);
+                             (int64_t)c.rc * 2 * gc, 0, 0, 0, c.stream);
 }
 
 static int dit_layer_attn_hp(Ctx& c, int l, int world, const void* q_all, void* o_all) {
@@ -293,9 +322,11 @@ static int dit_layer_attn_hp(Ctx& c, int l, int world, const void* q_all, void* 
   const int q_offset = st->cache_row0 - st->kv_lo;
   const uint16_t* kc = (const uint16_t*)st->kv_k[l];
   const uint16_t* vc = (const uint16_t*)st->kv_v[l];
-  return rtv_attn_fwd(q_all, kc + (size_t)st->kv_lo * rs, vc + (size_t)st->kv_lo * rs, o_all, 1, c.M, Lkv, hn, c.hd, 0, gc, 0,
-                      rs, 0, rs, 0, gc, 1.0f / sqrtf((float)c.hd), st->causal_block, st->causal_block > 0 ? q_offset : 0,
-                      RTV_DTYPE_BF16, c.stream);
+  KeyWindow kw = key_window(st);
+  (void)Lkv;
+  return rtv_attn_fwd_win(q_all, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, o_all, 1, c.M, kw.n0, kw.n1,
+                          kw.row1 - kw.row0, hn, c.hd, 0, gc, 0, rs, 0, rs, 0, gc, 1.0f / sqrtf((float)c.hd), st->causal_block,
+                          st->causal_block > 0 ? q_offset : 0, RTV_DTYPE_BF16, c.stream);
 }
 
 static int dit_layer_rest_hp(Ctx& c, int l, int world, const void* o_recv) {

@@ -157,6 +157,9 @@ struct RopeArgs {
   // of local row r to q_out + g*q_group_stride + r*group_cols and k/v + g*kv_group_stride + r*cache_row_stride.
   int group_cols;
   int64_t q_group_stride, kv_group_stride;
+  // rolling cache as a ring: logical cache row r >= ring_lo lives at ring_lo + (r - ring_lo + ring_shift) % ring_size
+  // (ring_size == 0: no ring, logical == physical); rows below ring_lo are the attention-sink rows and never move.
+  int ring_lo, ring_size, ring_shift;
 };
 
 __device__ __forceinline__ void rope8(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
@@ -213,7 +216,9 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
   const int pos_f = a.start_frame + f;
 
   const int gc = a.group_cols;
-  const size_t kv_row = gc ? (size_t)row : (size_t)(a.cache_row0 + grow);
+  size_t kv_row = gc ? (size_t)row : (size_t)(a.cache_row0 + grow);
+  if (!gc && a.ring_size > 0 && (int)kv_row >= a.ring_lo)
+    kv_row = (size_t)(a.ring_lo + ((int)kv_row - a.ring_lo + a.ring_shift) % a.ring_size);
   bf16_t* qo = a.q_out + (size_t)row * (gc ? gc : d);
   bf16_t* ko = a.k_cache + kv_row * a.cache_row_stride;
   bf16_t* vo = a.v_cache + kv_row * a.cache_row_stride;
@@ -314,8 +319,13 @@ namespace rtv {
 int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
                         int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
                         const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
-                        int64_t q_group_stride, int64_t kv_group_stride, rtv_stream_t stream) {
+                        int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
+                        rtv_stream_t stream) {
   if (M <= 0) return 0;
+  if (ring_size < 0 || ring_lo < 0 || ring_shift < 0 || (ring_size > 0 && ring_shift >= ring_size))
+    return set_error(-1, "qk_norm_rope_cache: bad ring (need ring_lo >= 0, 0 <= ring_shift < ring_size)");
+  if (ring_size > 0 && cache_row0 + row_offset + M > ring_lo + ring_size)
+    return set_error(-1, "qk_norm_rope_cache: rows beyond the end of the ring");
   if (num_heads <= 0 || d % num_heads) return set_error(-1, "qk_norm_rope_cache: d % num_heads != 0");
   const int hd = d / num_heads;
   if (d % 8 || d > EW_THREADS * 8 * EW_MAXC || hd % 8 || cache_row_stride % 8)
@@ -346,6 +356,9 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   a.group_cols = group_cols;
   a.q_group_stride = q_group_stride;
   a.kv_group_stride = kv_group_stride;
+  a.ring_lo = ring_lo;
+  a.ring_size = ring_size;
+  a.ring_shift = ring_shift;
   ProfScope prof(PROF_ROPE, (hipStream_t)stream, 6.0 * M * d * 2);
   hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
   return check_launch("qk_norm_rope_cache");
@@ -458,7 +471,16 @@ int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_
                            const void* wq, const void* wk, const void* rope_cs, int F, int gh, int gw,
                            int start_frame, int row_offset, rtv_stream_t stream) {
   return rtv::qk_norm_rope_launch(qkv, q_out, k_cache, v_cache, cache_row_stride, cache_row0, M, d, num_heads, eps, wq, wk,
-                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, stream);
+                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, 0, 0, 0, stream);
+}
+
+int rtv_qk_norm_rope_cache_ring(const void* qkv, void* q_out, void* k_cache, void* v_cache,
+                                int64_t cache_row_stride, int cache_row0, int M, int d, int num_heads, float eps,
+                                const void* wq, const void* wk, const void* rope_cs, int F, int gh, int gw,
+                                int start_frame, int row_offset, int ring_lo, int ring_size, int ring_shift,
+                                rtv_stream_t stream) {
+  return rtv::qk_norm_rope_launch(qkv, q_out, k_cache, v_cache, cache_row_stride, cache_row0, M, d, num_heads, eps, wq, wk,
+                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, ring_lo, ring_size, ring_shift, stream);
 }
 
 int rtv_modulation_table(const void* modulation, const void* e0, void* emod, int L, int F, int J, int J0,

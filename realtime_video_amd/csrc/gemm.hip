@@ -136,16 +136,6 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
       return launch_gemm8(p, f16, 4, stream);      // DMA in the LDS segment, no split-K
     case 5:
       return launch_gemm8(p, f16, 5, stream);      // + split-K of the tail round
-    case 6:
-      return launch_gemm9(p, f16, false, 3, stream);  // 256x256, k32-slab ring of 5, register-prefetched fragments
-    case 7:
-      return launch_gemm9(p, f16, true, 3, stream);   // + split-K of the tail round
-    case 71: case 72: case 73: case 74: case 75: case 76: case 77:
-      return launch_gemm9(p, f16, false, tile_cfg, stream);  // timing ablations of gemm9 (results are garbage)
-    case 61:
-      return launch_gemm9(p, f16, true, 1, stream);   // A/B: prefetch distance 1 slab
-    case 62:
-      return launch_gemm9(p, f16, true, 2, stream);   //                       2 slabs
     case 52:
       return launch_gemm8(p, f16, 9, stream);      // A/B: as 50 with the phase barrier BEFORE the lgkmcnt(0) (no difference)
     case 53:

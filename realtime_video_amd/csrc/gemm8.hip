@@ -23,6 +23,7 @@
 // of the tiles of the last, partial round over S workgroups; partial accumulators go through an fp32 slab
 // in a caller-provided workspace and the last arriver (agent-scope release / acquire + arrival counter)
 // sums them and runs the epilogue.
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_core.h"
@@ -265,11 +266,51 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   store_tile<F16, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
 }
 
-// ---------------------------------------------------------------- split-K workspace (caller-owned)
-static float* g_slabs = nullptr;
-static int* g_counters = nullptr;
-static size_t g_ws_units = 0;
-static int g_num_cus = 0;
+// ---------------------------------------------------------------- split-K workspaces (caller-owned)
+// One workspace = fp32 partial-tile slabs + arrival counters.  A workspace must never be shared by two launches that can run
+// at the same time, so they are registered per (device, stream): a launch on stream s of device d uses the workspace attached
+// to exactly (d, s), else the device-wide one attached with rtv_gemm_set_workspace (fine while ONE stream per device issues
+// split-K GEMMs), else it runs without split-K.
+struct SplitWorkspace {
+  int device;
+  hipStream_t stream;
+  bool any_stream;
+  float* slabs;
+  int* counters;
+};
+constexpr int MAX_WORKSPACES = 64;
+constexpr int MAX_DEVICES = 64;
+static SplitWorkspace g_ws[MAX_WORKSPACES];
+static int g_num_ws = 0;
+static int g_num_cus[MAX_DEVICES] = {0};
+static std::mutex g_ws_mu;
+
+static int attach_workspace(bool any_stream, hipStream_t stream, void* ptr, size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return set_error(-1, "gemm_set_workspace: cannot query the device");
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  int slot = -1;
+  for (int i = 0; i < g_num_ws; ++i)
+    if (g_ws[i].device == dev && g_ws[i].any_stream == any_stream && (any_stream || g_ws[i].stream == stream)) slot = i;
+  if (!ptr) {  // detach
+    if (slot >= 0) g_ws[slot] = g_ws[--g_num_ws];
+    return 0;
+  }
+  if (((uintptr_t)ptr) & 255) return set_error(-1, "gemm_set_workspace: pointer must be 256-byte aligned");
+  if (bytes < rtv_gemm_workspace_bytes()) return set_error(-1, "gemm_set_workspace: too small (rtv_gemm_workspace_bytes)");
+  if (slot < 0) {
+    if (g_num_ws == MAX_WORKSPACES) return set_error(-1, "gemm_set_workspace: too many workspaces attached");
+    slot = g_num_ws++;
+  }
+  SplitWorkspace w{dev, stream, any_stream, (float*)ptr, (int*)((char*)ptr + (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4)};
+  // arrival counters start at zero and every launch leaves them at zero (the reducer of a tile resets its counter)
+  if (hipMemset(w.counters, 0, (size_t)SPLIT_MAX_UNITS * sizeof(int)) != hipSuccess) {
+    if (slot == g_num_ws - 1) --g_num_ws;
+    return set_error(-1, "gemm_set_workspace: cannot zero the arrival counters");
+  }
+  g_ws[slot] = w;
+  return 0;
+}
 
 }  // namespace rtv
 
@@ -279,47 +320,54 @@ extern "C" size_t rtv_gemm_workspace_bytes(void) {
   return (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4 + (size_t)SPLIT_MAX_UNITS * 4 + 256;
 }
 
-extern "C" int rtv_gemm_set_workspace(void* ptr, size_t bytes) {
-  if (!ptr) {
-    g_slabs = nullptr;
-    g_counters = nullptr;
-    g_ws_units = 0;
-    return 0;
-  }
-  if (((uintptr_t)ptr) & 255) return set_error(-1, "gemm_set_workspace: pointer must be 256-byte aligned");
-  if (bytes < rtv_gemm_workspace_bytes()) return set_error(-1, "gemm_set_workspace: too small (rtv_gemm_workspace_bytes)");
-  g_slabs = (float*)ptr;
-  g_counters = (int*)((char*)ptr + (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4);
-  g_ws_units = SPLIT_MAX_UNITS;
-  // arrival counters start at zero and every launch leaves them at zero (the reducer of a tile resets its counter)
-  if (hipMemset(g_counters, 0, (size_t)SPLIT_MAX_UNITS * sizeof(int)) != hipSuccess)
-    return set_error(-1, "gemm_set_workspace: cannot zero the arrival counters");
-  return 0;
+extern "C" int rtv_gemm_set_workspace(void* ptr, size_t bytes) { return attach_workspace(true, nullptr, ptr, bytes); }
+
+extern "C" int rtv_gemm_set_stream_workspace(rtv_stream_t stream, void* ptr, size_t bytes) {
+  return attach_workspace(false, (hipStream_t)stream, ptr, bytes);
 }
 
 namespace rtv {
 
 int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream) {
-  if (g_num_cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-      return set_error(-1, "gemm: cannot query the device");
-    g_num_cus = prop.multiProcessorCount;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return set_error(-1, "gemm: cannot query the device");
+  float* slabs = nullptr;
+  int* counters = nullptr;
+  int G;
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (g_num_cus[dev] == 0) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return set_error(-1, "gemm: cannot query the device");
+      g_num_cus[dev] = prop.multiProcessorCount;
+    }
+    G = g_num_cus[dev];
+    for (int i = 0; i < g_num_ws && allow_split; ++i) {
+      const SplitWorkspace& w = g_ws[i];
+      if (w.device != dev) continue;
+      if (!w.any_stream && w.stream == stream) {   // exact (device, stream) match wins
+        slabs = w.slabs;
+        counters = w.counters;
+        break;
+      }
+      if (w.any_stream && !slabs) {
+        slabs = w.slabs;
+        counters = w.counters;
+      }
+    }
   }
-  const int G = g_num_cus;
   *sp = SplitArgs{T, 1, nullptr, nullptr};
   *grid = T;
   const int R = T % G;
-  if (allow_split && g_slabs && R > 0) {   // T < G (small M under context parallelism): every tile is a split tile
+  if (allow_split && slabs && R > 0) {   // T < G (small M under context parallelism): every tile is a split tile
     int S = G / R;                 // the split units of the partial round still fit one round
     if (S > 8) S = 8;
     if (S > nk / 4) S = nk / 4;    // keep >= 4 K-tiles per segment
-    if (S >= 2 && (size_t)R * S <= g_ws_units) {
+    if (S >= 2 && (size_t)R * S <= (size_t)SPLIT_MAX_UNITS) {
       sp->first_unit = T - R;
       sp->S = S;
-      sp->slabs = g_slabs;
-      sp->counters = g_counters;
+      sp->slabs = slabs;
+      sp->counters = counters;
       *grid = (T - R) + R * S;
     }
   }

@@ -1,4 +1,4 @@
-// In-launch split-K of the last, partial round of 256x256 output tiles (shared by gemm8.hip and gemm9.hip).
+// In-launch split-K of the last, partial round of 256x256 output tiles (gemm8.hip).
 //
 // T tiles on G CUs run as floor(T/G) full rounds plus R = T % G tiles; those R tiles would keep the chip at R/G
 // occupancy for a whole tile time.  Instead each of them is cut along K into S segments ("units", S = min(8, G/R)),

@@ -22,7 +22,6 @@ struct ProfScope {
 struct GemmParams;
 int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream);
 int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream);  // 256x256 ping-pong variant (gemm8.hip)
-int launch_gemm9(const GemmParams& p, bool f16, bool split, int dist, hipStream_t stream);
 // fp8 (e4m3) path, gemm_fp8.hip: dynamic per-tensor activation quantisation + 256x256 fp8 GEMM with the bf16 epilogue
 int launch_quantize_fp8(const uint16_t* x, int64_t ld, int M, int d, uint8_t* q, int64_t ldq, float* scale_out,
                         unsigned* amax_scratch, hipStream_t stream);
@@ -33,7 +32,8 @@ int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, i
 int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
                         int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
                         const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
-                        int64_t q_group_stride, int64_t kv_group_stride, rtv_stream_t stream);
+                        int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
+                        rtv_stream_t stream);
 int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rtv_stream_t stream);
 
 }  // namespace rtv

@@ -86,23 +86,53 @@ def attn_fwd(q, k, v, out=None, scale=None, causal_block=0, q_offset=0):
     return out
 
 
+def attn_fwd_win(q, k_cache, v_cache, seg0, seg1=(0, 0), out=None, scale=None):
+    """Attention over a key window made of two row ranges of a cache (rtv_attn_fwd_win): k_cache / v_cache [B, rows, H, 128],
+    seg = (first_row, n_rows).  How a ring-indexed rolling KV cache is attended without the reference's shift copy."""
+    _gpu(q, k_cache, v_cache)
+    B, Lq, H, D = q.shape
+    (r0, n0), (r1, n1) = seg0, seg1
+    rows = k_cache.shape[1]
+    if min(r0, n0, r1, n1) < 0 or r0 + n0 > rows or (n1 and r1 + n1 > rows):
+        raise ValueError("attn_fwd_win: segment outside the cache")
+    for t in (q, k_cache, v_cache):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("attention operands need dense [H, D] inner dims (BLHD layout)")
+    if out is None:
+        out = torch.empty((B, Lq, H, D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    k, v = k_cache[:, r0:], v_cache[:, r0:]
+    _lib.call("rtv_attn_fwd_win", _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Lq, n0, n1,
+              (r1 - r0) if n1 else 0, H, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+              out.stride(0), out.stride(1), float(scale), 0, 0, _dt(q), _stream())
+    return out
+
+
 # --------------------------------------------------------------------------------------- GEMM
 _gemm_ws = {}
 
 
-def ensure_gemm_workspace(device):
-    """Attach the split-K workspace (fp32 partial tiles + arrival counters, 64 MiB) used by tile_cfg 5."""
+def ensure_gemm_workspace(device, stream=None):
+    """Attach a split-K workspace (fp32 partial tiles + arrival counters, 64 MiB) for GEMM launches on `stream` (default: the
+    current stream) of `device`.  One workspace per (device, stream): two streams - or two devices - never share slabs or
+    arrival counters (rtv_gemm_set_stream_workspace)."""
     dev = torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if stream is None:
+        stream = torch.cuda.current_stream(idx).cuda_stream
+    key = (idx, int(stream))
     if key in _gemm_ws:
         return
     lib = _lib.load()
     lib.rtv_gemm_workspace_bytes.restype = ctypes.c_size_t
     lib.rtv_gemm_workspace_bytes.argtypes = []
     n = lib.rtv_gemm_workspace_bytes()
-    ws = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
-    off = (-ws.data_ptr()) % 256
-    _lib.call("rtv_gemm_set_workspace", ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(n))
+    with torch.cuda.device(idx):
+        ws = torch.zeros(n + 256, dtype=torch.uint8, device=torch.device("cuda", idx))
+        off = (-ws.data_ptr()) % 256
+        _lib.call("rtv_gemm_set_stream_workspace", ctypes.c_void_p(int(stream)), ctypes.c_void_p(ws.data_ptr() + off),
+                  ctypes.c_size_t(n))
     _gemm_ws[key] = ws
 
 
@@ -118,7 +148,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    if tile_cfg in (0, 5, 7, 50, 52, 53, 61, 62):
+    if tile_cfg in (0, 5, 50, 51, 52, 53):
         ensure_gemm_workspace(a.device)
     _lib.call("rtv_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K,
               _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame), int(row_offset),
@@ -187,8 +217,9 @@ def rmsnorm(x, weight, eps=1e-6, out=None):
 
 
 def qk_norm_rope_cache(qkv, k_cache, v_cache, cache_row0, num_heads, wq, wk, rope_cs, grid, start_frame,
-                       eps=1e-6, q_out=None, row_offset=0):
-    """qkv:[M,3d]; k_cache/v_cache:[kv_size,H,hd] views (row stride = stride(0)); grid=(F,gh,gw)."""
+                       eps=1e-6, q_out=None, row_offset=0, ring=(0, 0, 0)):
+    """qkv:[M,3d]; k_cache/v_cache:[kv_size,H,hd] views (row stride = stride(0)); grid=(F,gh,gw).
+    ring = (ring_lo, ring_size, ring_shift): logical row r >= ring_lo is stored at ring_lo + (r - ring_lo + ring_shift) % ring_size."""
     _gpu(qkv, k_cache, v_cache, wq, wk, rope_cs)
     M, d3 = qkv.shape
     d = d3 // 3
@@ -197,9 +228,10 @@ def qk_norm_rope_cache(qkv, k_cache, v_cache, cache_row0, num_heads, wq, wk, rop
         q_out = torch.empty((M, d), dtype=qkv.dtype, device=qkv.device)
     if cache_row0 + row_offset + M > k_cache.shape[0]:
         raise ValueError("KV-cache write out of range")
-    _lib.call("rtv_qk_norm_rope_cache", _ptr(qkv), _ptr(q_out), _ptr(k_cache), _ptr(v_cache),
+    _lib.call("rtv_qk_norm_rope_cache_ring", _ptr(qkv), _ptr(q_out), _ptr(k_cache), _ptr(v_cache),
               k_cache.stride(0), int(cache_row0), M, d, int(num_heads), float(eps), _ptr(wq), _ptr(wk),
-              _ptr(rope_cs), int(F), int(gh), int(gw), int(start_frame), int(row_offset), _stream())
+              _ptr(rope_cs), int(F), int(gh), int(gw), int(start_frame), int(row_offset),
+              int(ring[0]), int(ring[1]), int(ring[2]), _stream())
     return q_out
 
 

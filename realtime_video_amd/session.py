@@ -136,6 +136,11 @@ class GenerationSession:
     # release_server.py:542-560
     def init_models(self, models, params):
         pipe = models.pipeline
+        # Tokens per latent frame follow the session's resolution (1560 at 832x480).  The reference hard-codes 1560
+        # (causal_inference.py:35, causal_model.py:351), which at any other size leaves never-written gaps inside the attention
+        # window and a wrong RoPE frame; here cache sizing, `current_start` and the block mask all use the real count, which is
+        # also what makes the index-only cache reset below output-identical (every row of the window is written before it is read).
+        pipe.frame_seq_length = (self.latent_height // 2) * (self.latent_width // 2)
         attn_size = params.kv_cache_num_frames + pipe.num_frame_per_block
         for block in pipe.generator.model.blocks:
             block.self_attn.local_attn_size = -1

@@ -1,0 +1,362 @@
+// GEMM laboratory (NOT part of librtv_hip.so): instrumented / experimental builds of the 256x256x64 ping-pong projection
+// GEMM of csrc/gemm8.hip, compiled into scripts/micro/libgemm_lab.so and driven by scripts/gemm_lab.py on the GPU box.
+//   * s_memtime phase traces (where do the cycles of a K-tile go: LDS segment, counted-vmcnt wait, barrier waits, MFMA
+//     segment) and a per-workgroup timeline (start / end on the 100 MHz real-time counter + HW_ID / XCC_ID)
+//   * schedule variants selected by template bits, A/B-able inside one process
+// Same math as gemm8 (bias epilogue only), no split-K: use shapes with a whole number of tile rounds.
+#include <type_traits>
+
+#include "../../realtime_video_amd/csrc/gemm_core.h"
+
+namespace rtv {
+
+int set_error(int, const char*) { return -1; }
+
+namespace lab {
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_ROWS = 128;
+constexpr int HALF_BYTES = HALF_ROWS * BK * 2;  // 16 KiB
+constexpr int TILE_LDS = 8 * HALF_BYTES;        // 128 KiB
+constexpr int TRACE_LDS = 2 * 1024;             // per-K-tile stamps of waves 0 and 4 (u32[256] each)
+constexpr int THREADS = 512;
+
+enum { OPT_TRACE = 1, OPT_DSTAG = 2, OPT_NOPRIO = 4, OPT_BUFLD = 8, OPT_PRIO_STATIC = 16, OPT_DMA_EARLY = 32 };
+
+struct LabArgs {
+  unsigned* tile_stamps;   // [n_traced_blocks][2][256]  per-K-tile phase-1 start (low 32 bits of s_memtime), waves 0 / 4
+  unsigned* detail;        // [n_traced_blocks][2][32]   stamps inside K-tile `kt0`
+  unsigned long long* blocks;  // [grid][4]: realtime start, realtime end, memtime start, memtime end | hw_id/xcc in [3] high
+  int kt0;
+  int traced[4];           // block ids that dump their traces (-1 = none)
+};
+
+__device__ __forceinline__ int slot_off(int buf, int h) { return (buf * 4 + h) * HALF_BYTES; }
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+}  // namespace lab
+
+template <int OPT>
+__global__ __launch_bounds__(lab::THREADS, 2) void lab_gemm8(GemmParams p, lab::LabArgs la) {
+  using namespace lab;
+  constexpr bool TRACE = OPT & OPT_TRACE;
+  constexpr bool DSTAG = OPT & OPT_DSTAG;
+  constexpr bool NOPRIO = OPT & OPT_NOPRIO;
+  constexpr bool BUFLD = OPT & OPT_BUFLD;
+  constexpr bool PRIO_STATIC = OPT & OPT_PRIO_STATIC;
+  constexpr bool DMA_EARLY = OPT & OPT_DMA_EARLY;   // pieces after MFMA #1 and #3 instead of #2 and #5
+  typedef TileCfg<256, 256, 64, 2, 4> Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  unsigned long long rt0 = 0, mt0 = 0;
+  if (TRACE) {
+    rt0 = __builtin_amdgcn_s_memrealtime();
+    mt0 = __builtin_readcyclecounter();
+  }
+
+  const int nk_total = p.K / BK;
+  const int kt_begin = 0, kt_end = nk_total;
+  const int tile_id = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = tile_id / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = tile_id - group * per_group;
+  const int m0 = (first_m + in_group % gm) * BM;
+  const int n0 = (in_group / gm) * BN;
+
+  uint32_t src_off[4][2];  // [A0, A1, W0, W1][j] element offsets at k = 0
+  {
+    const int rsub = lane >> 3, cpos = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 64 + wave * 8 + rsub;
+      const int ch = swz(row, cpos) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gm_row = min(m0 + h * HALF_ROWS + row, p.M - 1);
+        const int gn_row = min(n0 + h * HALF_ROWS + row, p.N - 1);
+        src_off[h][j] = (uint32_t)gm_row * (uint32_t)p.lda + ch;
+        src_off[2 + h][j] = (uint32_t)gn_row * (uint32_t)p.ldw + ch;
+      }
+    }
+  }
+  __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  auto stage_piece = [&](int kt, int h, int j, auto chk) {
+    if (decltype(chk)::value && kt >= kt_end) return;
+    char* dst = smem + slot_off(kt & 1, h) + (j * 64 + wave * 8) * 128;
+    if (BUFLD) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(h < 2 ? rsrcA : rsrcW, (RTV_LDS void*)dst, 16, src_off[h][j] * 2u,
+                                               (unsigned)kt * (BK * 2), 0, 0);
+    } else {
+      const uint16_t* base = (h < 2 ? p.A : p.W) + (size_t)kt * BK;
+      dma16(base + src_off[h][j], dst);
+    }
+  };
+  auto stage_half = [&](int kt, int h) {
+    stage_piece(kt, h, 0, std::true_type{});
+    stage_piece(kt, h, 1, std::true_type{});
+  };
+
+  const int a_slot = wr;
+  const int b_slot = 2 + (wc >> 1);
+  const int b_row0 = (wc & 1) * 64;
+  u32x4 af[2][4];
+  u32x4 bfr[2][4];
+  u32x4 bnext[4];
+  auto read_a = [&](int buf, int mq) {
+    const char* s = smem + slot_off(buf, a_slot);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int row = mq * 64 + mb * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[mb][ks] = *(const u32x4*)(s + row * 128 + (swz(row, ks * 2 + g) << 4));
+    }
+  };
+  auto read_w = [&](int buf, int nq, u32x4 (&dst)[4]) {
+    const char* s = smem + slot_off(buf, b_slot);
+    const int row = b_row0 + nq * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const u32x4*)(s + row * 128 + (swz(row, ks * 2 + g) << 4));
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+#define L_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define L_BARRIER()                 \
+  do {                              \
+    L_FENCE();                      \
+    __builtin_amdgcn_s_barrier();   \
+    L_FENCE();                      \
+  } while (0)
+#define L_LDS_DONE()                                    \
+  do {                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
+    L_FENCE();                                          \
+  } while (0)
+
+  // detailed stamps of K-tile kt0: [phase][5] = phase begin, after the counted vmcnt (phases 2/4), after lgkmcnt(0),
+  // after barrier 1 (MFMA segment start), after the last MFMA issued
+  unsigned dt[4][5];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) dt[i][j] = 0;
+#define L_STAMP(ph, idx)                                                          \
+  do {                                                                            \
+    if (TRACE && detail) {                                                        \
+      L_FENCE();                                                                  \
+      dt[ph][idx] = (unsigned)__builtin_readcyclecounter();                       \
+      L_FENCE();                                                                  \
+    }                                                                             \
+  } while (0)
+
+  const int slot0 = DSTAG ? 1 + wc : (DMA_EARLY ? 1 : 2);
+  const int slot1 = DSTAG ? 5 + wc : (DMA_EARLY ? 3 : 5);
+  auto mma_quadrant = [&](int mq, int nq, int st_kt, int st_h, auto chk) {
+    if (!NOPRIO && !PRIO_STATIC) __builtin_amdgcn_s_setprio(1);
+    int n = 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        acc[mq * 2 + mb][nq] = Mfma32<false>::run(bfr[nq][ks], af[mb][ks], acc[mq * 2 + mb][nq]);
+        ++n;
+        if (DSTAG) {
+          if (n == slot0 || n == slot1) {
+            L_FENCE();
+            stage_piece(st_kt, st_h, n == slot0 ? 0 : 1, chk);
+            L_FENCE();
+          }
+        } else if (n == slot0 || n == slot1) {
+          L_FENCE();
+          stage_piece(st_kt, st_h, n == slot0 ? 0 : 1, chk);
+          L_FENCE();
+        }
+      }
+    if (!NOPRIO && !PRIO_STATIC) __builtin_amdgcn_s_setprio(0);
+  };
+
+  stage_half(kt_begin, 2);
+  stage_half(kt_begin, 3);
+  stage_half(kt_begin, 0);
+  stage_half(kt_begin, 1);
+  stage_half(kt_begin + 1, 2);
+  stage_half(kt_begin + 1, 3);
+  if (kt_begin + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  L_BARRIER();
+  if (wr == 1) L_BARRIER();
+  read_w(kt_begin & 1, 0, bnext);
+  L_LDS_DONE();
+  if (PRIO_STATIC && wr == 1) __builtin_amdgcn_s_setprio(1);
+
+  unsigned* tstamps = (unsigned*)(smem + TILE_LDS) + wr * 256;
+
+  auto k_tile = [&](const int kt, auto chk) {
+    constexpr bool CHK = decltype(chk)::value;
+    const int buf = kt & 1;
+    const bool detail = TRACE && kt == la.kt0;
+    if (TRACE) {
+      L_FENCE();
+      const unsigned t = (unsigned)__builtin_readcyclecounter();
+      if (wc == 0 && lane == 0 && kt < 256) tstamps[kt] = t;
+      L_FENCE();
+    }
+    // phase 1
+    L_STAMP(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bfr[0][ks] = bnext[ks];
+    read_a(buf, 0);
+    L_LDS_DONE();
+    L_STAMP(0, 2);
+    L_BARRIER();
+    L_STAMP(0, 3);
+    mma_quadrant(0, 0, kt + 1, 0, chk);
+    L_STAMP(0, 4);
+    L_BARRIER();
+    // phase 2
+    L_STAMP(1, 0);
+    read_w(buf, 1, bfr[1]);
+    if (!CHK || kt + 1 < kt_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    L_STAMP(1, 1);
+    L_LDS_DONE();
+    L_STAMP(1, 2);
+    L_BARRIER();
+    L_STAMP(1, 3);
+    mma_quadrant(0, 1, kt + 1, 1, chk);
+    L_STAMP(1, 4);
+    L_BARRIER();
+    // phase 3
+    L_STAMP(2, 0);
+    read_a(buf, 1);
+    L_LDS_DONE();
+    L_STAMP(2, 2);
+    L_BARRIER();
+    L_STAMP(2, 3);
+    mma_quadrant(1, 1, kt + 2, 2, chk);
+    L_STAMP(2, 4);
+    L_BARRIER();
+    // phase 4
+    L_STAMP(3, 0);
+    if (!CHK || kt + 1 < kt_end) read_w(buf ^ 1, 0, bnext);
+    if (!CHK || kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    L_STAMP(3, 1);
+    L_LDS_DONE();
+    L_STAMP(3, 2);
+    L_BARRIER();
+    L_STAMP(3, 3);
+    mma_quadrant(1, 0, kt + 2, 3, chk);
+    L_STAMP(3, 4);
+    L_BARRIER();
+  };
+  int kt = kt_begin;
+  for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});
+  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});
+  if (wr == 0) L_BARRIER();
+  if (PRIO_STATIC && wr == 1) __builtin_amdgcn_s_setprio(0);
+
+  unsigned long long mt1 = 0;
+  if (TRACE) mt1 = __builtin_readcyclecounter();
+  store_tile<false, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
+
+  if (TRACE) {
+    int slot = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (la.traced[i] == (int)blockIdx.x) slot = i;
+    if (slot >= 0) {
+      __syncthreads();
+      if (wc == 0 && lane < 20) {
+        unsigned v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            if (lane == i * 5 + j) v = dt[i][j];
+        la.detail[(slot * 2 + wr) * 32 + lane] = v;
+      }
+      for (int i = tid; i < 512; i += THREADS)
+        la.tile_stamps[slot * 512 + i] = ((unsigned*)(smem + TILE_LDS))[i];
+    }
+    if (tid == 0) {
+      const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long mt2 = __builtin_readcyclecounter();
+      const unsigned hw = __builtin_amdgcn_s_getreg(63492);   // HW_REG_HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg(63508);  // HW_REG_XCC_ID
+      unsigned long long* b = la.blocks + (size_t)blockIdx.x * 6;
+      b[0] = rt0;
+      b[1] = rt1;
+      b[2] = mt0;
+      b[3] = mt1;   // end of the K loop
+      b[4] = mt2;   // end of the epilogue
+      b[5] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+}
+
+template <int OPT>
+static int launch(GemmParams p, lab::LabArgs la, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  auto kern = lab_gemm8<OPT>;
+  const int lds = lab::TILE_LDS + ((OPT & lab::OPT_TRACE) ? lab::TRACE_LDS : 0);
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(lab::THREADS), lds, stream, p, la);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace rtv
+
+using namespace rtv;
+
+extern "C" int lab_gemm(int opt, const void* A, const void* W, void* C, const void* bias, int M, int N, int K,
+                        unsigned* tile_stamps, unsigned* detail, unsigned long long* blocks, int kt0, const int* traced,
+                        void* stream) {
+  GemmParams p;
+  p.A = (const uint16_t*)A;
+  p.W = (const uint16_t*)W;
+  p.C = (uint16_t*)C;
+  p.lda = K;
+  p.ldw = K;
+  p.ldc = N;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.bias = (const uint16_t*)bias;
+  p.act = 0;
+  p.gate = nullptr;
+  p.gate_stride = 0;
+  p.rows_per_frame = 0;
+  p.row_offset = 0;
+  p.residual = nullptr;
+  p.ldr = 0;
+  lab::LabArgs la;
+  la.tile_stamps = tile_stamps;
+  la.detail = detail;
+  la.blocks = blocks;
+  la.kt0 = kt0;
+  for (int i = 0; i < 4; ++i) la.traced[i] = traced ? traced[i] : -1;
+  hipStream_t s = (hipStream_t)stream;
+  switch (opt) {
+#define CASE(o) \
+  case o:       \
+    return launch<o>(p, la, s);
+    CASE(0) CASE(1) CASE(2) CASE(4) CASE(8) CASE(10) CASE(16) CASE(32) CASE(40) CASE(9)
+    default:
+      return -1;
+  }
+}

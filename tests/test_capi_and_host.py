@@ -66,41 +66,72 @@ def _fake_cache(L, kv_size):
              "global_end_index": 0, "local_end_index": 0} for _ in range(L)]
 
 
+def _window(m, kv, num_new, cur, fs=1560, **kw):
+    """_cache_window + commit: (cache_row0, kv_lo, kv_hi, start_frame, causal_block), ring = (ring_lo, ring_size, ring_shift)."""
+    row0, lo, hi, sf, cb, ring, commit = m._cache_window(kv, num_new, cur, fs, **kw)
+    commit()
+    return (row0, lo, hi, sf, cb), ring
+
+
 def test_cache_window_bookkeeping_server_path():
     """recompute then denoise steps at c = 3."""
     from realtime_video_amd.causal_model import CausalWanModel
     m = CausalWanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, device="cpu")
     kv = _fake_cache(2, 9360)
     # block 0: denoise at current_start 0, twice (second call overwrites the same rows)
-    assert m._cache_window(kv, 4680, 0, 1560) == (0, 0, 4680, 0, 0)
-    assert m._cache_window(kv, 4680, 0, 1560) == (0, 0, 4680, 0, 0)
+    assert _window(m, kv, 4680, 0) == ((0, 0, 4680, 0, 0), (0, 0, 0))
+    assert _window(m, kv, 4680, 0) == ((0, 0, 4680, 0, 0), (0, 0, 0))
     for c in kv:
         c["global_end_index"] = c["local_end_index"] = 0
     m.block_mask = m._prepare_blockwise_causal_attn_mask("cpu", num_frames=3, frame_seqlen=1560, num_frame_per_block=3)
-    assert m._cache_window(kv, 4680, 4680, 1560) == (0, 0, 4680, 0, 4680)   # recompute ignores current_start
+    assert _window(m, kv, 4680, 4680)[0] == (0, 0, 4680, 0, 4680)   # recompute ignores current_start
+    with pytest.raises(RuntimeError):
+        m._cache_window(kv, 9361, 0, 1560)                           # recompute context larger than the cache
     m.block_mask = None
-    assert m._cache_window(kv, 4680, 4680, 1560) == (4680, 0, 9360, 3, 0)
-    assert m._cache_window(kv, 4680, 4680, 1560) == (4680, 0, 9360, 3, 0)
+    assert _window(m, kv, 4680, 4680)[0] == (4680, 0, 9360, 3, 0)
+    assert _window(m, kv, 4680, 4680)[0] == (4680, 0, 9360, 3, 0)
     assert all(c["global_end_index"] == 9360 and c["local_end_index"] == 9360 for c in kv)
     with pytest.raises(RuntimeError):
         m._cache_window(kv, 4680, 9360, 1560)   # would run past the (c+3)-frame cache
+    # the bookkeeping is committed only once the forward has been issued: a call that is not committed changes nothing
+    m._cache_window(kv, 4680, 4680, 1560)
+    assert all(c["global_end_index"] == 9360 and c["local_end_index"] == 9360 for c in kv)
+    # the attention window is fixed at construction (causal_model.py:192), whatever init_models writes afterwards
+    m2 = CausalWanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64, local_attn_size=4, device="cpu")
+    m2.blocks[0].self_attn.local_attn_size = -1
+    assert m2.blocks[0].self_attn.max_attention_size == 4 * 1560
 
 
 def test_cache_window_rolling_eviction():
-    """causal_model.py:359-385 with local_attn_size=6, sink_size=1: indices of SURVEY Appendix B."""
-    from realtime_video_amd.causal_model import CausalWanModel
+    """causal_model.py:359-385 with local_attn_size=6, sink_size=1: indices of SURVEY Appendix B.  The eviction is a ring
+    advance (no copy): the cache tensors are never touched by the bookkeeping, the live rows in logical order
+    (`cache_row_map`) are what the reference's shifted cache holds."""
+    from realtime_video_amd.causal_model import CausalWanModel, cache_row_map
     m = CausalWanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=1, text_dim=64, local_attn_size=6, sink_size=1,
                        device="cpu")
     kv = _fake_cache(1, 6 * 1560)
     kv[0]["k"][:] = torch.arange(6 * 1560).view(1, -1, 1, 1).to(torch.bfloat16)
-    seen = []
+    before = kv[0]["k"].clone()
+    seen, rings = [], []
     for b in range(4):
-        row0, lo, hi, sf, cb = m._cache_window(kv, 4680, b * 4680, 1560)
+        (row0, lo, hi, sf, cb), ring = _window(m, kv, 4680, b * 4680)
         seen.append((kv[0]["global_end_index"], kv[0]["local_end_index"], row0, lo, hi, sf))
+        rings.append(ring)
     assert seen == [(4680, 4680, 0, 0, 4680, 0), (9360, 9360, 4680, 0, 9360, 3),
                     (14040, 9360, 4680, 0, 9360, 6), (18720, 9360, 4680, 0, 9360, 9)]
-    # the sink frame stayed in place, the rest was shifted left by one block
-    assert float(kv[0]["k"][0, 0, 0, 0]) == 0.0 and float(kv[0]["k"][0, 1559, 0, 0]) == float(torch.tensor(1559.).to(torch.bfloat16))
+    assert rings == [(0, 0, 0), (0, 0, 0), (1560, 7800, 4680), (1560, 7800, 1560)]
+    assert torch.equal(kv[0]["k"], before)                     # zero eviction copies
+    rows = cache_row_map(kv[0])
+    assert rows[:1560].tolist() == list(range(1560))           # the sink frame stays in place
+    # after two evictions of 4680 rows the logical rows behind the sink start 9360 rows further along the ring
+    assert rows[1560].item() == 1560 + (9360 % 7800) and sorted(rows.tolist()) == list(range(9360))
+    # the reference's shift copy is still available (context-parallel exchanges move contiguous row blocks)
+    kv2 = _fake_cache(1, 6 * 1560)
+    kv2[0]["k"][:] = torch.arange(6 * 1560).view(1, -1, 1, 1).to(torch.bfloat16)
+    for b in range(3):
+        _, ring = _window(m, kv2, 4680, b * 4680, ring=False)
+        assert ring == (0, 0, 0)
+    assert float(kv2[0]["k"][0, 0, 0, 0]) == 0.0 and float(kv2[0]["k"][0, 1560, 0, 0]) == float(torch.tensor(6240.).to(torch.bfloat16))
 
 
 def test_conv_weight_packing_is_im2col_order():
@@ -233,13 +264,33 @@ def test_attention_plugin_installs_into_the_reference_modules():
                 setattr(m, n, v)
 
 
+def _key_window_rows(lo, hi, S, R, shift):
+    """Python restatement of dit_forward.hip key_window(): the <= 2 physical row ranges of the logical window [lo, hi)."""
+    if R <= 0 or hi <= S:
+        segs = [(lo, hi - lo)]
+    else:
+        rl = max(lo, S)
+        n = hi - rl
+        p0 = S + (rl - S + shift) % R
+        first = n if p0 + n <= S + R else S + R - p0
+        sink = S - lo if lo < S else 0
+        if first == n:
+            segs = [(p0, n)] if sink == 0 else ([(lo, sink + n)] if p0 == S else [(lo, sink), (p0, n)])
+        else:
+            segs = [(lo if sink else S, sink + n - first), (p0, first)]
+    assert len(segs) <= 2
+    rows = [r for a, n in segs for r in range(a, a + n)]
+    assert len(rows) == len(set(rows))
+    return set(rows)
+
+
 def test_cache_window_random_sequences_match_the_reference_rule():
     """Property test of the KV bookkeeping (must match the reference EXACTLY): 150 random call sequences - window
     sizes with and without attention sinks, 1- and 3-frame calls, repeated calls on the same block (denoising steps) - run
     through CausalWanModel._cache_window on CPU cache tensors whose rows carry their write stamp, against the index
     arithmetic and the eviction copy of causal_model.py:349-392 restated inline."""
     import random
-    from realtime_video_amd.causal_model import CausalWanModel
+    from realtime_video_amd.causal_model import CausalWanModel, cache_row_map
     rng = random.Random(7)
     fs = 1560
     for trial in range(150):
@@ -271,14 +322,23 @@ def test_cache_window_random_sequences_match_the_reference_rule():
             local_start = local_end - num_new
             if local_start < 0 or local_end > kv_size:
                 break                                       # the reference would index out of range here; skip the tail
-            row0, lo, hi, start_frame, cb = m._cache_window(kv, num_new, cur, fs)
+            use_ring = trial % 3 != 0                       # every third trial: the shift-copy mode of the CP path
+            (row0, lo, hi, start_frame, cb), (r_lo, r_size, r_shift) = _window(m, kv, num_new, cur, fs, ring=use_ring)
             stamp += 1
-            kv[0]["k"][0, row0:row0 + num_new] = stamp    # what the forward's cache write does
+            # what the forward's cache write does (rtv_qk_norm_rope_cache_ring): logical row -> physical row
+            rr = torch.arange(row0, row0 + num_new)
+            phys = torch.where(rr >= r_lo, r_lo + (rr - r_lo + r_shift) % r_size, rr) if r_size else rr
+            assert use_ring or r_size == 0
+            kv[0]["k"][0, phys] = stamp
             ref_k[local_start:local_end] = stamp
             g_end, l_end = current_end, local_end
             assert (row0, lo, hi, start_frame, cb) == (local_start, max(0, local_end - max_att), local_end, cur // fs, 0), trial
             assert (kv[0]["global_end_index"], kv[0]["local_end_index"]) == (g_end, l_end), trial
-            assert torch.equal(kv[0]["k"][0, :, 0, 0], ref_k), trial
+            # the live rows in logical order are exactly the reference's (shifted) cache rows [0, local_end)
+            assert torch.equal(kv[0]["k"][0, cache_row_map(kv[0]), 0, 0], ref_k[:l_end]), trial
+            # and the two physical ranges the attention kernel walks cover exactly the window [lo, hi)
+            live = set(cache_row_map(kv[0])[lo:hi].tolist())
+            assert _key_window_rows(lo, hi, r_lo, r_size, r_shift) == live, trial
             prev_cur, prev_new = cur, num_new
             cur = current_end
 
@@ -322,7 +382,7 @@ def test_cache_window_matches_the_real_reference_model_on_random_sequences():
             lat = torch.randn(1, frames, 16, 60, 104, generator=g).to(torch.bfloat16)
             with torch.inference_mode():
                 wr(lat, {"prompt_embeds": [ctx]}, torch.ones([1, frames], dtype=torch.int64) * 500, rkv, rca, current_start=cur)
-            row0, lo, hi, sf, cb = ours._cache_window(okv, frames * fs, cur, fs)
+            (row0, lo, hi, sf, cb), _ = _window(ours, okv, frames * fs, cur, fs)
             assert (int(rkv[0]["global_end_index"]), int(rkv[0]["local_end_index"])) == \
                 (okv[0]["global_end_index"], okv[0]["local_end_index"]), (trial, call)
             written = rkv[0]["k"][0].float().abs().sum((-1, -2)) > 0

@@ -480,3 +480,107 @@ def test_attention_random_shape_sweep(ops):
             ref = _attn_ref(q, k, v)
         assert max_abs(out, ref) <= 2.5e-2, (case, Lq, Lkv, H)
         assert rel_l2(out, ref) <= 1.2e-2, (case, Lq, Lkv, H)
+
+
+# ----------------------------------------------------------------------------------------- the plug-in entry points
+def test_attention_plugin_entries_run_on_device(ops, golden):
+    """The drop-in boundary itself executed on the GPU: `attention(...)` (wan/modules/attention.py:150-212
+    contract), the `sageattn_func` stand-in (wan/modules/sage.py:12-19, BHLD) and the registered custom op
+    `torch.ops.rtv.attn_fwd`, with K/V as strided views of a K/V-interleaved cache arena (how causal_model.py:386-390
+    hands the cache window to the backend), against the reference's own `attention()` output (ops.pt)."""
+    from realtime_video_amd import attention as plug
+    g = golden("ops.pt")
+    q, k, v = (g[n].to(DEV) for n in ("attn_q", "attn_k", "attn_v"))
+    Lkv, H = k.shape[1], k.shape[2]
+    arena = torch.zeros(1, Lkv + 9, 2, H, 128, dtype=torch.bfloat16, device=DEV)
+    arena[:, 4:4 + Lkv, 0], arena[:, 4:4 + Lkv, 1] = k, v
+    kc, vc = arena[:, 4:4 + Lkv, 0], arena[:, 4:4 + Lkv, 1]
+    assert not kc.is_contiguous()
+    before = arena.clone()
+    o_attn = plug.attention(q, kc, vc)
+    o_op = torch.ops.rtv.attn_fwd(q, kc, vc)
+    o_sage = plug.sageattn_func(q.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2)).transpose(1, 2)
+    assert torch.equal(arena, before)                       # the backend must not write the cache it reads
+    for o in (o_attn, o_op, o_sage):
+        assert o.shape == g["attn_out"].shape and o.dtype == torch.bfloat16
+        assert max_abs(o.cpu(), g["attn_out"]) <= 2e-2
+    assert o_attn.is_contiguous() and torch.equal(o_attn, o_op) and torch.equal(o_attn, o_sage)
+    assert torch.equal(o_attn, ops.attn_fwd(q, kc, vc))     # == the raw C-ABI call
+    # dtype contract (attention.py:166-178): non-half inputs are computed in `dtype` and returned in the input dtype
+    o32 = plug.attention(q.float(), kc.float(), vc.float())
+    assert o32.dtype == torch.float32 and torch.equal(o32, o_attn.float())
+    # softmax_scale / q_scale
+    ref = _attn_ref(q * 0.5, kc, vc)
+    assert max_abs(plug.attention(q, kc, vc, q_scale=0.5), ref) <= 2e-2
+    assert max_abs(plug.attention(q, kc, vc, softmax_scale=0.5 / math.sqrt(128)), ref) <= 2e-2
+    # block-causal recompute mask through the op
+    S = min(q.shape[1], Lkv)
+    lim = torch.clamp((torch.arange(S, device=DEV) // 128 + 1) * 128, max=S)
+    o_bc = torch.ops.rtv.attn_fwd(q[:, :S], kc[:, :S], vc[:, :S], -1.0, 128, 0)
+    assert max_abs(o_bc, _attn_ref(q[:, :S], kc[:, :S], vc[:, :S], lim)) <= 2e-2
+    with pytest.raises(NotImplementedError):
+        plug.attention(q, kc, vc, causal=True)
+
+
+def test_attention_custom_op_opcheck():
+    """torch.library.opcheck on `rtv::attn_fwd` (schema, fake-tensor propagation, AOT dispatch) - the registration the
+    reference does for sageattention (sage.py:12-19) so that traced graphs survive."""
+    import realtime_video_amd.attention  # noqa: F401  (registers the op)
+    q = _randn(1, 200, 2, 128, seed=1)
+    cache = _randn(1, 333, 2, 2, 128, seed=2)
+    k, v = cache[:, 10:310, 0], cache[:, 10:310, 1]
+    torch.library.opcheck(torch.ops.rtv.attn_fwd.default, (q, k, v), {"softmax_scale": -1.0, "causal_block": 0, "q_offset": 0})
+    torch.library.opcheck(torch.ops.rtv.attn_fwd.default, (q, k[:, :256], v[:, :256]),
+                          {"softmax_scale": 0.05, "causal_block": 64, "q_offset": 56})
+    fake = torch.library.opcheck   # noqa: F841
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        fq = torch.empty(1, 200, 2, 128, dtype=torch.bfloat16, device=DEV)
+        fk = torch.empty(1, 300, 2, 128, dtype=torch.bfloat16, device=DEV)
+        out = torch.ops.rtv.attn_fwd(fq, fk, fk)
+        assert out.shape == (1, 200, 2, 128) and out.dtype == torch.bfloat16
+
+
+# ----------------------------------------------------------------------------------------- ring-indexed rolling cache (K8)
+@pytest.mark.parametrize("seg0,seg1", [((1560, 3000), (7000, 2360)), ((0, 64), (100, 64)), ((5, 1), (900, 1)),
+                                       ((4680, 4680), (0, 4680)), ((10, 100), (0, 0)), ((3, 77), (200, 1003))])
+def test_attention_two_segment_window_equals_concatenated_keys(ops, seg0, seg1):
+    """rtv_attn_fwd_win walks two row ranges of the cache in place; the result is bit-identical to the one-segment kernel
+    on a contiguous copy of the same keys (same virtual tiling) and within tolerance of the fp32 definition."""
+    (r0, n0), (r1, n1) = seg0, seg1
+    H, Lq = 2, 300
+    q = _randn(1, Lq, H, 128, seed=1)
+    arena = _randn(1, 9400, 2, H, 128, seed=2)
+    kc, vc = arena[:, :, 0], arena[:, :, 1]
+    out = ops.attn_fwd_win(q, kc, vc, seg0, seg1)
+    k = torch.cat([kc[:, r0:r0 + n0], kc[:, r1:r1 + n1]], 1).contiguous()
+    v = torch.cat([vc[:, r0:r0 + n0], vc[:, r1:r1 + n1]], 1).contiguous()
+    assert torch.equal(out, ops.attn_fwd(q, k, v))
+    assert max_abs(out, _attn_ref(q, k, v)) <= 2e-2
+
+
+def test_qk_norm_rope_cache_ring_write(ops):
+    """rtv_qk_norm_rope_cache_ring stores logical cache row r >= ring_lo at ring_lo + (r - ring_lo + shift) % size: the rows it
+    writes are the plain kernel's rows, permuted; everything else in the cache is untouched."""
+    from realtime_video_amd.rope import rope_cos_sin_table
+    F_, gh, gw, H = 2, 6, 10, 2
+    M, d = F_ * gh * gw, 256
+    qkv = _randn(M, 3 * d, seed=1)
+    wq, wk = _randn(d, seed=2), _randn(d, seed=3)
+    cs = rope_cos_sin_table(128).to(DEV)
+    rows = 400
+    base = _randn(rows, 2, H, 128, seed=4)
+    plain, ring = base.clone(), base.clone()
+    row0, lo, size, shift = 150, 40, 300, 233        # rows [150, 270) wrap: 40 + (110 + 233 .. ) % 300
+    q0 = ops.qk_norm_rope_cache(qkv, plain[:, 0], plain[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5)
+    q1 = ops.qk_norm_rope_cache(qkv, ring[:, 0], ring[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5, ring=(lo, size, shift))
+    assert torch.equal(q0, q1)
+    r = torch.arange(row0, row0 + M)
+    phys = lo + (r - lo + shift) % size
+    assert phys.min() >= lo and phys.max() < lo + size and (phys[1:] < phys[:-1]).any()      # really wraps
+    assert torch.equal(ring[phys.to(DEV)], plain[row0:row0 + M])
+    mask = torch.ones(rows, dtype=torch.bool)
+    mask[phys] = False
+    assert torch.equal(ring[mask.to(DEV)], base[mask.to(DEV)])
+    with pytest.raises(RuntimeError):
+        ops.qk_norm_rope_cache(qkv, ring[:, 0], ring[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5, ring=(lo, 100, 3))
