@@ -8,6 +8,7 @@ namespace rtv {
 template <bool F16, int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
   typedef TileCfg<BM, BN, BK, WM, WN> Cfg;
+  static_assert(Cfg::TN == 2 && Cfg::NW * Cfg::TM * 32 * 128 <= 2 * Cfg::STAGE_BYTES, "LDS epilogue geometry");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -81,7 +82,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     mma_stage<F16, Cfg, BK>(sA, sA + Cfg::A_BYTES, a_row0, b_row0, lane, acc);
   }
 
-  store_tile<F16, Cfg>(p, m0 + a_row0, n0 + b_row0, lane, acc);
+  // epilogue through LDS (coalesced 16-byte rows, gemm_core.h) whenever the output / residual rows allow it
+  const bool wide = !((p.ldc | (p.residual ? p.ldr : 0)) & 7) && !(((uintptr_t)p.C | (uintptr_t)p.residual) & 15);
+  if (wide) {
+    __syncthreads();   // every wave is done reading the staged tiles
+    store_tile_lds<F16, Cfg::TM>(p, m0 + a_row0, n0 + b_row0, lane, smem + wave * (Cfg::TM * 32 * 128), acc);
+  } else {
+    store_tile<F16, Cfg>(p, m0 + a_row0, n0 + b_row0, lane, acc);
+  }
 }
 
 template <bool F16, int BM, int BN, int BK, int WM, int WN>
@@ -119,7 +127,7 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
     // along K over the idle CUs, scripts/cp_gemm_shapes.py)
     if (!f16 && ((p.K >= 2048 && tiles256 >= 128) || tiles256 >= 640 || (p.K >= 8192 && tiles256 >= 64)))
-      return launch_gemm8(p, f16, 1, stream);
+      return launch_gemm8(p, f16, true, stream);
     tile_cfg = 1;
   }
   switch (tile_cfg) {
@@ -133,17 +141,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
       return f16 ? launch_cfg<true, 256, 256, 64, 2, 4>(p, stream)
                  : launch_cfg<false, 256, 256, 64, 2, 4>(p, stream);
     case 4:
-      return launch_gemm8(p, f16, 4, stream);      // DMA in the LDS segment, no split-K
+      return launch_gemm8(p, f16, false, stream);   // 256x256 ping-pong kernel, no split-K
     case 5:
-      return launch_gemm8(p, f16, 5, stream);      // + split-K of the tail round
-    case 52:
-      return launch_gemm8(p, f16, 9, stream);      // A/B: as 50 with the phase barrier BEFORE the lgkmcnt(0) (no difference)
-    case 53:
-      return launch_gemm8(p, f16, 17, stream);     // A/B: as 50 with the K-tile bounds checks inside the steady-state loop
     case 50:
-      return launch_gemm8(p, f16, 1, stream);      // = the default for large problems: DMA between MFMAs + split-K
-    case 51:
-      return launch_gemm8(p, f16, 3, stream);      //                                            = 1
+      return launch_gemm8(p, f16, true, stream);    // + split-K of the tail round = the default for large problems
     default:
       return set_error(-1, "gemm: unknown tile config");
   }

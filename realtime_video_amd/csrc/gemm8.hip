@@ -1,28 +1,32 @@
-// 256x256x64 "ping-pong" projection GEMM for gfx950 (tile configs 5 / 6): the high-throughput variant of
-// gemm.hip for the large DiT linears (same math, same fused epilogue, same C ABI).
+// 256x256x64 "ping-pong" projection GEMM for gfx950 (tile configs 4 / 5): the high-throughput variant of gemm.hip for
+// the large DiT linears (same math, same fused epilogue, same C ABI).
 //
-// One workgroup = 8 waves on one CU, two waves per SIMD.  Waves 0-3 ("group 0", output rows 0-127) and
-// waves 4-7 ("group 1", rows 128-255) run the SAME phase program staggered by one s_barrier, so on every
-// SIMD one wave is in its MFMA segment while its partner is in its LDS segment:
+// One workgroup = 8 waves on one CU, two waves per SIMD.  Waves 0-3 ("group 0", output rows 0-127) and waves 4-7
+// ("group 1", rows 128-255) run the SAME phase program staggered by one s_barrier, so on every SIMD one wave is in its
+// MFMA segment while its partner is in its LDS segment.  A K-tile (64 deep) is TWO phases of 16 MFMA 32x32x16 each:
 //
-//     group 0:  lds(p) | B | mfma(p) | B | lds(p+1) | B | mfma(p+1) | B ...
-//     group 1:       B | lds(p) | B | mfma(p)    | B | lds(p+1) | B ...
+//   interval 4t+0:  g0  LDS  X(t): W[n0], W[n1], A[m0]  (16 ds_read_b128)        g1  MFMA Y(t-1)
+//   interval 4t+1:  g0  MFMA X(t): (m0; n0, n1) + stage A0, A1 of tile t+2       g1  LDS  X(t)
+//   interval 4t+2:  g0  LDS  Y(t): A[m1] (8 reads), s_waitcnt vmcnt(4)           g1  MFMA X(t)
+//   interval 4t+3:  g0  MFMA Y(t): (m1; n0, n1) + stage W0, W1 of tile t+2       g1  LDS  Y(t)
 //
-// A K-tile (64 deep) is 4 phases; a phase computes one 64x32 quadrant of the wave's 128x64 output
-// (8 MFMA 32x32x16) and stages ONE 128x64 half-tile of a future K-tile with global_load_lds.  The two
-// DMA pieces of a phase are issued BETWEEN MFMAs (an LDS-DMA costs 60-180 issue cycles inside an LDS
-// segment but hides behind the 32-cycle MFMA issue slots: +15 % measured); the LDS segments carry only
-// ds_read_b128s (8/4/8/4 per phase), retired right after the phase's first barrier.
-// LDS: 2 K-tile buffers x {A rows 0-127, A rows 128-255, W rows 0-127, W rows 128-255} x 16 KiB = 128 KiB.
-// DMA runs ~1.5 K-tiles ahead and is retired by COUNTED s_waitcnt vmcnt(2) (never 0 in steady state).
-// Schedule per K-tile t (slots of buffer t&1 are re-filled for tile t+2):
-//     p1: read A[m0]          mfma (m0,n0) + stage A0(t+1)     p2: read W[n1], vmcnt(2)   mfma (m0,n1) + stage A1(t+1)
-//     p3: read A[m1]          mfma (m1,n1) + stage W0(t+2)     p4: read W[n0](t+1), vmcnt(2)  mfma (m1,n0) + stage W1(t+2)
+// Round-2 measurements that shaped it (scripts/gemm_lab.py, profiles/r02_gemm_*): with 8 MFMAs per segment (the round-1
+// schedule) a barrier interval cost ~365 cycles for 256 cycles of MFMA issue (K-tile 3000-3300 cycles for 2048 of MFMA); with
+// 16 per segment the fixed cost per interval (barrier, role switch, DMA issue) is paid half as often: 2470 cycles per
+// K-tile.  And the direct register-layout epilogue (8-byte stores at a row stride) took a third of the kernel: the epilogue
+// now goes through LDS (store_tile_lds, gemm_core.h).  Together 986 -> 1335 TF/s on 4096x16384x5120 (hipBLASLt: 1538).
 //
-// Tail-wave quantisation (e.g. 380 tiles on 256 CUs = 1.48 rounds) is removed by splitting the K range
-// of the tiles of the last, partial round over S workgroups; partial accumulators go through an fp32 slab
-// in a caller-provided workspace and the last arriver (agent-scope release / acquire + arrival counter)
-// sums them and runs the epilogue.
+// LDS (160 KiB): A has THREE K-tile buffers, W two, each {rows 0-127, rows 128-255} x 16 KiB.  Half-tiles are staged with
+// `buffer_load_dwordx4 ... lds` (lane offset in a VGPR that never changes, K offset in an SGPR: no per-piece VALU), 4 pieces
+// per MFMA segment, issued between MFMAs.  A(t+2) goes to A buffer (t+2)%3 - last read in Y(t-1) - and W(t+2) to W buffer
+// t&1 - last read in X(t) - so every piece is in flight for >= 3 barrier intervals (~1700 cycles) before the ONE counted
+// wait per K-tile (vmcnt(4) in Y's LDS segment: everything but the 4 youngest pieces) retires it; it is read one phase
+// later (after a barrier every wave has passed).  The LDS image is lane-linear per DMA piece; the bank swizzle is applied
+// to the per-lane source chunk and again on the ds_read_b128 (same involution).
+//
+// Tail-wave quantisation (e.g. 380 tiles on 256 CUs = 1.48 rounds) is removed by splitting the K range of the tiles of the
+// last, partial round over S workgroups; partial accumulators go through an fp32 slab in a caller-provided workspace and
+// the last arriver (agent-scope release / acquire + arrival counter) sums them and runs the epilogue.
 #include <mutex>
 #include <type_traits>
 
@@ -34,20 +38,26 @@ namespace rtv {
 
 namespace g8 {
 constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int HALF_ROWS = 128;
-constexpr int HALF_BYTES = HALF_ROWS * BK * 2;  // 16 KiB
-constexpr int LDS_BYTES = 8 * HALF_BYTES;       // 128 KiB
+constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB: 128 rows of one operand
+constexpr int A_OFF = 0;                     // 3 K-tile buffers x 2 halves
+constexpr int W_OFF = 6 * HALF_BYTES;        // 2 K-tile buffers x 2 halves
+constexpr int LDS_BYTES = 10 * HALF_BYTES;   // 160 KiB
 constexpr int THREADS = 512;
-
-__device__ __forceinline__ int slot_off(int buf, int h) { return (buf * 4 + h) * HALF_BYTES; }
 // swizzled 16-byte chunk position inside a 128-byte row (involution; conflict-free ds_read_b128)
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
-
 }  // namespace g8
 
-template <bool F16, int NL, bool SYNC_FIRST = false, bool PEEL = true>
+#ifdef RTV_GEMM_TIMELINE   // lab builds only (scripts/micro/build_gemm_timeline.sh): per-workgroup start / end stamps
+__device__ unsigned long long* g_timeline = nullptr;   // [grid][4]: realtime start, after K loop, end, (seg << 32 | tile)
+#endif
+
+template <bool F16>
 __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
+#ifdef RTV_GEMM_TIMELINE
+  const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl_t1 = 0;
+#endif
   typedef TileCfg<256, 256, 64, 2, 4> Cfg;  // epilogue geometry: 4 x 2 blocks of 32x32 per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -58,7 +68,6 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   const int l31 = lane & 31, g = lane >> 5;
 
   // ---- workgroup -> (tile, K segment)
-  const int ntiles = p.tiles_m * p.tiles_n;
   const int nk_total = p.K / BK;
   int tile_id, seg, unit, kt_begin, kt_end;
   const bool is_split = split_unit_of_block(sp, blockIdx.x, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
@@ -71,11 +80,10 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   const int in_group = tile_id - group * per_group;
   const int m0 = (first_m + in_group % gm) * BM;
   const int n0 = (in_group / gm) * BN;
-  (void)ntiles;
 
-  // ---- DMA geometry: a half-tile is 2 wave-wide pieces per wave; piece j of wave w fills rows
-  //      j*64 + w*8 .. +8 (lane -> row + lane/8, chunk slot lane%8), source chunk pre-swizzled.
-  uint32_t src_off[4][2];  // [A0, A1, W0, W1][j] element offsets at k = 0
+  // ---- DMA geometry: a half-tile is 2 wave-wide pieces per wave; piece j of wave w fills rows j*64 + w*8 .. +8
+  //      (lane -> row + lane/8, chunk slot lane%8), source chunk pre-swizzled.  BYTE offsets at k = 0.
+  uint32_t src_off[4][2];  // [A0, A1, W0, W1][j]
   {
     const int rsub = lane >> 3, cpos = lane & 7;
 #pragma unroll
@@ -84,34 +92,31 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
       const int ch = swz(row, cpos) * 8;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int gm_row = min(m0 + h * HALF_ROWS + row, p.M - 1);
-        const int gn_row = min(n0 + h * HALF_ROWS + row, p.N - 1);
-        src_off[h][j] = (uint32_t)gm_row * (uint32_t)p.lda + ch;
-        src_off[2 + h][j] = (uint32_t)gn_row * (uint32_t)p.ldw + ch;
+        const int gm_row = min(m0 + h * 128 + row, p.M - 1);
+        const int gn_row = min(n0 + h * 128 + row, p.N - 1);
+        src_off[h][j] = ((uint32_t)gm_row * (uint32_t)p.lda + ch) * 2u;
+        src_off[2 + h][j] = ((uint32_t)gn_row * (uint32_t)p.ldw + ch) * 2u;
       }
     }
   }
+  // raw buffer descriptors over the whole operands (no bounds clamp needed: rows are clamped above, K is a multiple of 64)
+  __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
   // `chk` (std::true_type / false_type): whether the K-tile index still has to be compared with kt_end.  The steady-state
   // iterations (kt + 2 < kt_end) stage unconditionally - no scalar compare + branch around every DMA piece inside the loop.
-  auto stage_piece = [&](int kt, int h, int j, auto chk) {  // kt: K-tile, h: 0..3 = A0, A1, W0, W1, j: piece
+  auto stage_piece = [&](int kt, int a3, int h, int j, auto chk) {  // h: 0..3 = A0, A1, W0, W1; a3 = kt % 3
     if (decltype(chk)::value && kt >= kt_end) return;
-    const uint16_t* base = (h < 2 ? p.A : p.W) + (size_t)kt * BK;
-    dma16(base + src_off[h][j], smem + slot_off(kt & 1, h) + (j * 64 + wave * 8) * 128);
-  };
-  auto stage_half = [&](int kt, int h) {
-    stage_piece(kt, h, 0, std::true_type{});
-    stage_piece(kt, h, 1, std::true_type{});
+    const int slot = h < 2 ? A_OFF + (a3 * 2 + h) * HALF_BYTES : W_OFF + ((kt & 1) * 2 + (h - 2)) * HALF_BYTES;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(h < 2 ? rsrcA : rsrcW, (RTV_LDS void*)(smem + slot + (j * 64 + wave * 8) * 128), 16,
+                                             src_off[h][j], (unsigned)kt * (BK * 2), 0, 0);
   };
 
-  // ---- fragment addressing: A rows of this wave live in half-tile `wr`, W rows in half-tile 2 + (wc >> 1)
-  const int a_slot = wr;
-  const int b_slot = 2 + (wc >> 1);
+  // ---- fragment addressing: A rows of this wave live in half `wr`, W rows in half wc >> 1
   const int b_row0 = (wc & 1) * 64;
   u32x4 af[2][4];   // current 64-row A half: [m-block][k-step]
   u32x4 bfr[2][4];  // both 32-column W blocks of the K-tile: [n-block][k-step]
-  u32x4 bnext[4];   // W[n0] fragments of the NEXT K-tile (prefetched in phase 4: load segments are 8/4/8/4 reads)
-  auto read_a = [&](int buf, int mq) {
-    const char* s = smem + slot_off(buf, a_slot);
+  auto read_a = [&](int a3, int mq) {
+    const char* s = smem + A_OFF + (a3 * 2 + wr) * HALF_BYTES;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       const int row = mq * 64 + mb * 32 + l31;
@@ -119,11 +124,14 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
       for (int ks = 0; ks < 4; ++ks) af[mb][ks] = *(const u32x4*)(s + row * 128 + (swz(row, ks * 2 + g) << 4));
     }
   };
-  auto read_w = [&](int buf, int nq, u32x4 (&dst)[4]) {
-    const char* s = smem + slot_off(buf, b_slot);
-    const int row = b_row0 + nq * 32 + l31;
+  auto read_w = [&](int wb) {
+    const char* s = smem + W_OFF + (wb * 2 + (wc >> 1)) * HALF_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const u32x4*)(s + row * 128 + (swz(row, ks * 2 + g) << 4));
+    for (int nq = 0; nq < 2; ++nq) {
+      const int row = b_row0 + nq * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[nq][ks] = *(const u32x4*)(s + row * 128 + (swz(row, ks * 2 + g) << 4));
+    }
   };
 
   f32x16 acc[4][2];
@@ -146,124 +154,108 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  \
     G8_FENCE();                                         \
   } while (0)
-  // Phase = LDS segment [fragment reads, NL DMA pieces, counted vmcnt] | barrier | lgkmcnt(0) |
-  //         MFMA segment [8 MFMA + (2 - NL) DMA pieces between them] | barrier.
-  // SYNC_FIRST (A/B config 52, NL = 0): the phase's first barrier comes BEFORE the lgkmcnt(0) that retires the
-  // fragment reads, so the LDS latency of the reads overlaps the barrier wait instead of preceding it; measured equal to
-  // the default order (scripts/cold_gemm.py).  It stays WAR-safe: a wave retires its reads before its MFMAs,
-  // i.e. before the phase's SECOND barrier; the earliest restage of a slot (W0 of the current buffer, staged in phase 3,
-  // last read in phase 2) is issued after the stager's first barrier of phase 3, which every wave of its own group
-  // passes after that second barrier and every wave of the other group (one barrier behind) passes as its own second
-  // barrier of phase 2.  RAW is unchanged: the counted vmcnt still precedes the first barrier of phases 2 / 4 and the data
-  // is read a phase later.  With SYNC_FIRST = false the reads are retired before the barrier (the NL >= 1 variants need
-  // that: their LDS-segment DMA restages a slot one phase after its last read).
-#define G8_PHASE_SYNC()   \
-  do {                    \
-    if (SYNC_FIRST) {     \
-      G8_BARRIER();       \
-      G8_LDS_DONE();      \
-    } else {              \
-      G8_LDS_DONE();      \
-      G8_BARRIER();       \
-    }                     \
-  } while (0)
 
-  // MFMA segment of one phase: 8 MFMA on one 64x32 quadrant (+ the DMA pieces not issued in the LDS segment)
-  auto mma_quadrant = [&](int mq, int nq, int st_kt, int st_h, auto chk) {
+  // MFMA segment: 16 MFMA on the 64 x 64 half (mq; n0, n1) with 4 DMA pieces between them (halves h0, h0 + 1 of K-tile
+  // st_kt): an LDS-DMA costs 60-180 issue cycles inside an LDS segment but ~10 behind an MFMA.
+  auto mma_half = [&](int mq, int st_kt, int st_a3, int h0, auto chk) {
     __builtin_amdgcn_s_setprio(1);
     int n = 0;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb) {
-        acc[mq * 2 + mb][nq] = Mfma32<F16>::run(bfr[nq][ks], af[mb][ks], acc[mq * 2 + mb][nq]);
-        ++n;
-        if ((NL == 0 && n == 2) || (NL <= 1 && n == 5)) {
-          G8_FENCE();
-          stage_piece(st_kt, st_h, n == 2 ? 0 : 1, chk);
-          G8_FENCE();
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          acc[mq * 2 + mb][nq] = Mfma32<F16>::run(bfr[nq][ks], af[mb][ks], acc[mq * 2 + mb][nq]);
+          ++n;
+          if ((n & 3) == 2) {
+            G8_FENCE();
+            stage_piece(st_kt, st_a3, h0 + (n >> 3), (n >> 2) & 1, chk);
+            G8_FENCE();
+          }
         }
-      }
     __builtin_amdgcn_s_setprio(0);
   };
-  auto stage_lds_seg = [&](int st_kt, int st_h, auto chk) {  // the NL pieces issued in the LDS segment (after the reads)
-    if (NL >= 1) {
-      G8_FENCE();
-      stage_piece(st_kt, st_h, NL == 2 ? 0 : 0, chk);
-      if (NL == 2) stage_piece(st_kt, st_h, 1, chk);
-      G8_FENCE();
-    }
-  };
-  // NL == 1: piece 0 goes in the LDS segment, piece 1 after MFMA #5.  Counted waits: `KEEP` = pieces of the two
-  // youngest half-tiles that may stay in flight at the wait point of phases 2 / 4.
-  constexpr int KEEP = (NL == 2) ? 4 : (NL == 1 ? 3 : 2);
 
-  // ---- prologue: first K-tile complete + the W halves of the second (what p3/p4 of the previous tile would stage)
-  stage_half(kt_begin, 2);
-  stage_half(kt_begin, 3);
-  stage_half(kt_begin, 0);
-  stage_half(kt_begin, 1);
-  stage_half(kt_begin + 1, 2);
-  stage_half(kt_begin + 1, 3);
-  if (kt_begin + 1 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // ---- prologue: the first two K-tiles complete (what X / Y of two earlier tiles would have staged)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      const int h = (hh + 2) & 3;   // W0, W1, A0, A1
+      stage_piece(kt_begin + t, t, h, 0, std::true_type{});
+      stage_piece(kt_begin + t, t, h, 1, std::true_type{});
+    }
+  if (kt_begin + 1 < kt_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   G8_BARRIER();
   if (wr == 1) G8_BARRIER();  // stagger: group 1 runs one barrier behind group 0
-  read_w(kt_begin & 1, 0, bnext);
-  G8_LDS_DONE();
 
-#define G8_WAIT_KEEP()                                                          \
-  do {                                                                          \
-    if (KEEP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");             \
-    else if (KEEP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");        \
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                       \
-  } while (0)
-
+  int a3 = 0;  // (kt - kt_begin) % 3
   auto k_tile = [&](const int kt, auto chk) {
     constexpr bool CHK = decltype(chk)::value;
-    const int buf = kt & 1;
-    // ---------------- phase 1: quadrant (m0, n0), stages A0(kt+1)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bfr[0][ks] = bnext[ks];
-    read_a(buf, 0);
-    stage_lds_seg(kt + 1, 0, chk);
-    G8_PHASE_SYNC();
-    mma_quadrant(0, 0, kt + 1, 0, chk);
+    const int a3n = a3 == 0 ? 2 : a3 - 1;   // A buffer of K-tile kt + 2
+    // ---------------- phase X: (m0; n0, n1); stages A0, A1 of K-tile kt + 2 (their buffer was last read in Y(kt - 1))
+    read_w(kt & 1);
+    read_a(a3, 0);
+    G8_LDS_DONE();
     G8_BARRIER();
-    // ---------------- phase 2: quadrant (m0, n1), stages A1(kt+1); retire W0/W1(kt+1): phase 4 prefetches W[n0] of
-    //                  K-tile kt+1 from them.  In flight afterwards: A0(kt+1) and the LDS-segment pieces of A1(kt+1).
-    read_w(buf, 1, bfr[1]);
-    stage_lds_seg(kt + 1, 1, chk);
-    if (!CHK || kt + 1 < kt_end) G8_WAIT_KEEP();
-    G8_PHASE_SYNC();
-    mma_quadrant(0, 1, kt + 1, 1, chk);
+    mma_half(0, kt + 2, a3n, 0, chk);
     G8_BARRIER();
-    // ---------------- phase 3: quadrant (m1, n1), stages W0(kt+2) (the W slots of this buffer are free now)
-    read_a(buf, 1);
-    stage_lds_seg(kt + 2, 2, chk);
-    G8_PHASE_SYNC();
-    mma_quadrant(1, 1, kt + 2, 2, chk);
-    G8_BARRIER();
-    // ---------------- phase 4: quadrant (m1, n0), stages W1(kt+2); retire A0/A1(kt+1).
-    if (!CHK || kt + 1 < kt_end) read_w(buf ^ 1, 0, bnext);
-    stage_lds_seg(kt + 2, 3, chk);
-    if (!CHK || kt + 2 < kt_end) G8_WAIT_KEEP();
+    // ---------------- phase Y: (m1; n0, n1); stages W0, W1 of K-tile kt + 2 (this tile's W buffer, last read in X(kt)).
+    //                  The counted wait leaves the 4 pieces of X(kt) in flight and retires W(kt + 1) and everything older:
+    //                  X(kt + 1) reads A(kt + 1) / W(kt + 1) one phase later.
+    read_a(a3, 1);
+    if (!CHK || kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    G8_PHASE_SYNC();
-    mma_quadrant(1, 0, kt + 2, 3, chk);
+    G8_LDS_DONE();
     G8_BARRIER();
+    mma_half(1, kt + 2, a3n, 2, chk);
+    G8_BARRIER();
+    a3 = a3 == 2 ? 0 : a3 + 1;
   };
   int kt = kt_begin;
-  if constexpr (PEEL)   // (PEEL = false, A/B config 53: every iteration keeps the checks)
-    for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});   // steady state: tiles kt+1 and kt+2 exist
-  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});          // last two K-tiles
-  if (wr == 0) G8_BARRIER();  // group 0 closes the stagger
+  for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});   // steady state: K-tile kt + 2 exists
+  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});        // last two K-tiles
+  if (wr == 0) G8_BARRIER();  // group 0 closes the stagger: every LDS read and DMA of the loop is retired
 
   // ---- split-K fix-up: publish the partial tile, last arriver reduces (placement-independent agent-scope
   //      release/acquire; the slab is a per-lane register image, so the reduce is a plain elementwise add)
+#ifdef RTV_GEMM_TIMELINE
+  tl_t1 = __builtin_amdgcn_s_memrealtime();
+  bool reducer = true;
+  if (is_split) reducer = split_k_reduce(acc, sp, unit, seg, tile_id, smem, tid, wave, lane);
+  if (!reducer) {
+    if (g_timeline && tid == 0) {
+      unsigned long long* t = g_timeline + (size_t)blockIdx.x * 4;
+      t[0] = tl_t0;
+      t[1] = tl_t1;
+      t[2] = __builtin_amdgcn_s_memrealtime();
+      t[3] = ((unsigned long long)(seg + 1) << 32) | (unsigned)tile_id;
+    }
+    return;
+  }
+#else
   if (is_split && !split_k_reduce(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
+#endif
 
-  store_tile<F16, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
+  // ---- epilogue through LDS when the output / residual rows allow 16-byte accesses (always on the DiT path)
+  const bool wide = !((p.ldc | (p.residual ? p.ldr : 0)) & 7) && !(((uintptr_t)p.C | (uintptr_t)p.residual) & 15);
+  if (wide) {
+    if (is_split) __syncthreads();   // the reducer's flag word lives in smem[0..4)
+    store_tile_lds<F16, 4>(p, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * 128), acc);
+  } else {
+    store_tile<F16, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
+  }
+#ifdef RTV_GEMM_TIMELINE
+  if (g_timeline && tid == 0) {
+    unsigned long long* t = g_timeline + (size_t)blockIdx.x * 4;
+    t[0] = tl_t0;
+    t[1] = tl_t1;
+    t[2] = __builtin_amdgcn_s_memrealtime();
+    t[3] = ((unsigned long long)(is_split ? seg + 1 : 0) << 32) | (unsigned)tile_id | (is_split ? 0x80000000u : 0u);
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- split-K workspaces (caller-owned)
@@ -316,6 +308,12 @@ static int attach_workspace(bool any_stream, hipStream_t stream, void* ptr, size
 
 using namespace rtv;
 
+#ifdef RTV_GEMM_TIMELINE
+extern "C" int rtv_gemm_debug_timeline(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" size_t rtv_gemm_workspace_bytes(void) {
   return (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4 + (size_t)SPLIT_MAX_UNITS * 4 + 256;
 }
@@ -356,7 +354,7 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       }
     }
   }
-  *sp = SplitArgs{T, 1, nullptr, nullptr};
+  *sp = SplitArgs{T, 1, nullptr, nullptr, 0};
   *grid = T;
   const int R = T % G;
   if (allow_split && slabs && R > 0) {   // T < G (small M under context parallelism): every tile is a split tile
@@ -368,17 +366,18 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       sp->S = S;
       sp->slabs = slabs;
       sp->counters = counters;
+      sp->tail_tiles = R;
       *grid = (T - R) + R * S;
     }
   }
   return 0;
 }
 
-template <bool F16, int NL, bool SYNC_FIRST = false, bool PEEL = true>
+template <bool F16>
 static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   p.tiles_m = (p.M + g8::BM - 1) / g8::BM;
   p.tiles_n = (p.N + g8::BN - 1) / g8::BN;
-  auto kern = gemm8_kernel<F16, NL, SYNC_FIRST, PEEL>;
+  auto kern = gemm8_kernel<F16>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES);
@@ -393,16 +392,11 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   return check_launch("gemm8");
 }
 
-int launch_gemm8(const GemmParams& p, bool f16, int variant, hipStream_t stream) {
-  // variant: bit 0 = split-K of the tail round; bits 1.. = DMA pieces issued in the LDS segment (0, 1, 2)
-  const bool split = variant & 1;
-  const int nl = (variant >> 1) & 3;
-  if (variant & 8) return launch_gemm8_t<false, 0, true>(p, split, stream);  // A/B: barrier before the lgkmcnt wait
-  if (variant & 16) return launch_gemm8_t<false, 0, false, false>(p, split, stream);  // A/B: bounds checks kept in the loop
-  if (f16) return launch_gemm8_t<true, 2>(p, split, stream);
-  if (nl == 0) return launch_gemm8_t<false, 0>(p, split, stream);
-  if (nl == 1) return launch_gemm8_t<false, 1>(p, split, stream);
-  return launch_gemm8_t<false, 2>(p, split, stream);
+int launch_gemm8(const GemmParams& p, bool f16, bool split, hipStream_t stream) {
+  // the buffer descriptors address the operands with 32-bit byte offsets
+  if ((size_t)p.M * p.lda * 2 > 0x7fffffffull || (size_t)p.N * p.ldw * 2 > 0x7fffffffull)
+    return set_error(-1, "gemm8: operand larger than 2 GiB");
+  return f16 ? launch_gemm8_t<true>(p, split, stream) : launch_gemm8_t<false>(p, split, stream);
 }
 
 }  // namespace rtv

@@ -44,6 +44,9 @@ struct Mfma32<false> {
   static __device__ __forceinline__ float to_f32(uint16_t v) { return bf16_to_f32(v); }
   static __device__ __forceinline__ uint16_t from_f32(float v) { return f32_to_bf16(v); }
   static __device__ __forceinline__ float round(float v) { return round_bf16(v); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+  static __device__ __forceinline__ float lo_f32(uint32_t u) { return __uint_as_float(u << 16); }
+  static __device__ __forceinline__ float hi_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 };
 template <>
 struct Mfma32<true> {
@@ -54,6 +57,9 @@ struct Mfma32<true> {
   static __device__ __forceinline__ float to_f32(uint16_t v) { return f16_to_f32(v); }
   static __device__ __forceinline__ uint16_t from_f32(float v) { return f32_to_f16(v); }
   static __device__ __forceinline__ float round(float v) { return round_f16(v); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) { return pack_f16x2(lo, hi); }
+  static __device__ __forceinline__ float lo_f32(uint32_t u) { return f16_to_f32((uint16_t)(u & 0xffff)); }
+  static __device__ __forceinline__ float hi_f32(uint32_t u) { return f16_to_f32((uint16_t)(u >> 16)); }
 };
 
 // LDS tile geometry shared by the GEMM and the implicit-GEMM conv kernels.
@@ -175,6 +181,92 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, int m_base, int 
         }
       }
     }
+  }
+}
+
+// Epilogue through LDS: coalesced global accesses for the output and the fused residual.
+//
+// The MFMA register layout gives every lane ONE output row and 4 consecutive columns per quad, so storing it directly
+// (store_tile above) issues 8-byte accesses at a row stride: 32 different cache lines per instruction.  Measured on the
+// 256x256 tile (scripts/gemm_lab.py, profiles/r02_gemm_lab_v2_vs_v1.log): that store tail costs 85-130k cycles per tile,
+// a third of the kernel.  Here each wave first writes its TM*32 x 64 block to a wave-private LDS image of 128-byte rows
+// (16-byte chunk c of row r at chunk c ^ (r & 7), its 8-byte halves swapped when (r >> 3) & 1: conflict-free ds_write_b64 and
+// ds_read_b128), then every lane reads 16 contiguous bytes of a row, so residual loads and output stores are whole
+// 128-byte lines per 8 lanes: 18k cycles per tile.
+// Same rounding points as epilogue_quad (y = bf16(acc + bias); y = bf16(act(y)); t = bf16(y * gate); out = bf16(res + t)):
+// a value is only rounded when another operation follows; the staged value is t, the residual is added in f32 afterwards.
+// `img`: TM*32*128 bytes of LDS owned by this wave; the caller guarantees nobody still reads that LDS (barrier).
+template <bool F16, int TM>
+__device__ __forceinline__ void store_tile_lds(const GemmParams& p, int m_base, int n_base, int lane, char* img,
+                                               f32x16 (&acc)[TM][2]) {
+  typedef Mfma32<F16> T;
+  const int l31 = lane & 31, g = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int row = mi * 32 + l31;
+    const uint16_t* gp = nullptr;
+    if (p.gate) gp = p.gate + (size_t)((p.row_offset + min(m_base + row, p.M - 1)) / p.rows_per_frame) * p.gate_stride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int nc = min(n_base + ni * 32 + rq * 8 + g * 4, p.N - 4);
+        float v[4] = {acc[mi][ni][rq * 4 + 0], acc[mi][ni][rq * 4 + 1], acc[mi][ni][rq * 4 + 2], acc[mi][ni][rq * 4 + 3]};
+        if (p.bias) {
+          const u32x2 b = *(const u32x2*)(p.bias + nc);
+          v[0] += T::lo_f32(b[0]);
+          v[1] += T::hi_f32(b[0]);
+          v[2] += T::lo_f32(b[1]);
+          v[3] += T::hi_f32(b[1]);
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(T::round(v[i]));
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = silu(T::round(v[i]));
+        }
+        if (p.gate) {
+          const u32x2 gg = *(const u32x2*)(gp + nc);
+          v[0] = T::round(v[0]) * T::lo_f32(gg[0]);
+          v[1] = T::round(v[1]) * T::hi_f32(gg[0]);
+          v[2] = T::round(v[2]) * T::lo_f32(gg[1]);
+          v[3] = T::round(v[3]) * T::hi_f32(gg[1]);
+        }
+        u32x2 o;
+        o[0] = T::pack2(v[0], v[1]);
+        o[1] = T::pack2(v[2], v[3]);
+        const int chunk = (ni * 4 + rq) ^ (row & 7);
+        const int half = g ^ ((row >> 3) & 1);
+        *(u32x2*)(img + row * 128 + chunk * 16 + half * 8) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const int rsub = lane >> 3, c = lane & 7;
+  const int n = n_base + c * 8;
+  const bool n_ok = n < p.N;
+  constexpr int PASSES = TM * 4;   // 8 rows per pass
+  u32x4 res[PASSES];
+  if (p.residual) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int m = min(m_base + ps * 8 + rsub, p.M - 1);
+      res[ps] = *(const u32x4*)(p.residual + (size_t)m * p.ldr + min(n, p.N - 8));
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int row = ps * 8 + rsub;
+    const int m = m_base + row;
+    u32x4 t = *(const u32x4*)(img + row * 128 + ((c ^ (row & 7)) << 4));
+    if ((row >> 3) & 1) t = u32x4{t[2], t[3], t[0], t[1]};
+    if (p.residual) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        t[i] = T::pack2(T::lo_f32(t[i]) + T::lo_f32(res[ps][i]), T::hi_f32(t[i]) + T::hi_f32(res[ps][i]));
+    }
+    if (m < p.M && n_ok) *(u32x4*)(p.C + (size_t)m * p.ldc + n) = t;
   }
 }
 

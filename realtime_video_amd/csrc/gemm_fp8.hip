@@ -228,7 +228,13 @@ __global__ __launch_bounds__(gf8::THREADS, 2) void gemm_fp8_kernel(GemmParams p,
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= sc;
-  store_tile<false, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
+  const bool wide = !((p.ldc | (p.residual ? p.ldr : 0)) & 7) && !(((uintptr_t)p.C | (uintptr_t)p.residual) & 15);
+  if (wide) {
+    if (is_split) __syncthreads();
+    store_tile_lds<false, 4>(p, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * 128), acc);   // gemm_core.h
+  } else {
+    store_tile<false, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
+  }
 }
 
 // ------------------------------------------------------------------ dynamic per-tensor activation quantisation

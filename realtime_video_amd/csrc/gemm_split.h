@@ -19,6 +19,7 @@ struct SplitArgs {
   float* slabs;     // [units][SPLIT_SLAB_FLOATS]
   int* counters;    // [split tiles]: zero between launches (zeroed when the workspace is attached; the reducer of a
                     // tile puts its counter back to zero)
+  int tail_tiles;   // R: number of split tiles (block ids first_unit .. first_unit + R * S)
 };
 
 // host: decide the split for T tiles of nk K-tiles each (defined in gemm8.hip, which owns the workspace pointers).
@@ -26,6 +27,11 @@ struct SplitArgs {
 int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream);
 
 // device: block id -> (tile, K segment).  Returns true when this workgroup is a split unit.
+// The units of the tail round are laid out for L2 locality like the full tiles are: every XCD gets a contiguous chunk of the
+// (segment-major) unit list, i.e. ~R*S/8 consecutive tiles of ONE K segment - a compact block of the supertile order whose
+// workgroups share A / W panels through that XCD's L2.  (Unit -> XCD round robin, the round-1 layout, put the two K halves of
+// a tile and unrelated tiles on every XCD: each unit streamed its own panels, ~11 TB/s of L2 misses for the 232 units of the
+// QKV projection, and the split tail was slower than an unsplit fifth round: profiles/r02_gemm_shapes_*.log.)
 __device__ __forceinline__ bool split_unit_of_block(const SplitArgs& sp, int bid, int nk_total, int* tile_id, int* unit,
                                                     int* seg, int* kt_begin, int* kt_end) {
   *seg = 0;
@@ -33,9 +39,11 @@ __device__ __forceinline__ bool split_unit_of_block(const SplitArgs& sp, int bid
   if (bid < sp.first_unit) {
     *tile_id = xcd_remap(bid, sp.first_unit);
   } else {
-    *unit = bid - sp.first_unit;
-    *tile_id = sp.first_unit + *unit / sp.S;
-    *seg = *unit % sp.S;
+    const int v = xcd_remap(bid - sp.first_unit, sp.tail_tiles * sp.S);
+    *seg = v / sp.tail_tiles;
+    const int tl = v - *seg * sp.tail_tiles;
+    *tile_id = sp.first_unit + tl;
+    *unit = tl * sp.S + *seg;      // slab index: the S slabs of a tile are adjacent
   }
   const bool is_split = *unit >= 0 && sp.S > 1;
   *kt_begin = is_split ? (int)((long)nk_total * *seg / sp.S) : 0;
@@ -48,22 +56,26 @@ __device__ __forceinline__ bool split_unit_of_block(const SplitArgs& sp, int bid
 // `smem` needs 4 free bytes at offset 0 (the K loop is over).  8 waves, acc = [4][2] blocks of 32x32 per wave.
 __device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[4][2], const SplitArgs& sp, int unit, int seg, int tile_id,
                                                char* smem, int tid, int wave, int lane) {
-  float4* slab = (float4*)(sp.slabs + (size_t)unit * SPLIT_SLAB_FLOATS);
+  // Publish with WRITE-THROUGH (sc1) 16-byte stores + a per-wave drain, then ONE relaxed agent-scope ticket: no release
+  // fence.  A release fence is `buffer_wbl2`, which writes back every dirty line of the XCD's L2 - at the end of a GEMM that
+  // is megabytes of other workgroups' freshly written output tiles (measured: the 16 split units of the FFN-in GEMM cost
+  // 64 us instead of ~30; profiles/r02_gemm_shapes.log).  The reducer takes one agent-scope acquire and reads plain.
+  __amdgpu_buffer_rsrc_t slab =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(sp.slabs + (size_t)unit * SPLIT_SLAB_FLOATS), 0, SPLIT_SLAB_FLOATS * 4, 0x00020000);
 #pragma unroll
   for (int blk = 0; blk < 8; ++blk)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x16& a = acc[blk >> 1][blk & 1];
-      slab[((wave * 8 + blk) * 4 + q) * 64 + lane] = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
+      const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab, (((wave * 8 + blk) * 4 + q) * 64 + lane) * 16, 0,
+                                             /*aux: sc1*/ 16);
     }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
   __syncthreads();
   int* flag = (int*)smem;
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0)
     *flag = __hip_atomic_fetch_add(sp.counters + (tile_id - sp.first_unit), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   __syncthreads();
   const int ticket = *flag;
   if (ticket != sp.S - 1) return false;  // not the last arriver: done

@@ -18,8 +18,40 @@ vp = ctypes.c_void_p
 lib.lab_gemm.argtypes = [ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int,
                          ctypes.POINTER(ctypes.c_int), vp]
 lib.lab_gemm.restype = ctypes.c_int
-OPT_NAMES = {0: "base", 2: "dma-stagger", 4: "no-setprio", 8: "buffer-load", 10: "buffer+stagger", 16: "static-prio",
-             32: "dma-early", 40: "buffer+early"}
+OPT_NAMES = {0: "base", 8: "buffer-load", 100: "v2 (16-MFMA segments, LDS epilogue)", 102: "v2, old epilogue"}
+lib.lab_gemm_v2_epi.argtypes = [vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
+                                ctypes.c_int, ctypes.c_int, vp]
+lib.lab_gemm_v2_epi.restype = ctypes.c_int
+
+
+def epilogue_parity():
+    """v2 with every fused epilogue vs the product kernel (same K order -> bit-identical), ragged M and N edges included."""
+    ok = True
+    for (M, N, K) in [(4680, 5120, 5120), (585, 1536, 1024), (300, 264, 128), (4680, 13824, 512)]:
+        g = torch.Generator(device="cuda").manual_seed(M + N)
+        a = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda", generator=g) * K ** -0.5).to(torch.bfloat16)
+        b = torch.randn(N, device="cuda", generator=g).to(torch.bfloat16)
+        gate = torch.randn(3, 6, N, device="cuda", generator=g).to(torch.bfloat16)
+        res = torch.randn(M, N, device="cuda", generator=g).to(torch.bfloat16)
+        rpf = (M + 2) // 3
+        for act, use_gate, use_res in [(0, False, False), (1, False, False), (0, True, True), (2, False, True), (0, False, True)]:
+            ref = ops.gemm(a, w, bias=b, act=act, gate=gate[0, 2] if use_gate else None, gate_stride=6 * N,
+                           rows_per_frame=rpf if use_gate else 0, residual=res if use_res else None, tile_cfg=4)
+            for old in (0, 1):
+                c = torch.full((M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+                p = lambda t: vp(t.data_ptr()) if t is not None else vp(0)
+                st = lib.lab_gemm_v2_epi(p(a), p(w), p(c), p(b), act, p(gate[0, 2]) if use_gate else vp(0), 6 * N,
+                                         rpf if use_gate else 0, p(res) if use_res else vp(0), M, N, K, old,
+                                         vp(torch.cuda.current_stream().cuda_stream))
+                torch.cuda.synchronize()
+                same = torch.equal(c, ref)
+                ok &= same
+                if not same:
+                    d = (c.float() - ref.float()).abs()
+                    print(f"!! v2 epilogue mismatch M{M} N{N} K{K} act{act} gate{use_gate} res{use_res} old_epi{old}: max {d.max().item()} "
+                          f"bad {int((d > 0).sum())}")
+    print("v2 epilogue parity vs product kernel (bit-exact):", "OK" if ok else "FAILED", flush=True)
 
 
 def lab(opt, a, w, c, bias, stamps=None, detail=None, blocks=None, kt0=-1, traced=None):
@@ -147,11 +179,52 @@ def trace(opt=1):
     return res
 
 
+def trace_v2():
+    M, N, K = 4096, 16384, 5120
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device="cuda").to(torch.bfloat16)
+    c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    grid = (M // 256) * (N // 256)
+    traced = [0, 9, 300, 1000]
+    import numpy as np
+    for opt in (101, 103):
+        for kt0 in (30, 60):
+            stamps = torch.zeros(4 * 512, dtype=torch.int32, device="cuda")
+            detail = torch.zeros(4 * 2 * 32, dtype=torch.int32, device="cuda")
+            blocks = torch.zeros(grid * 6, dtype=torch.int64, device="cuda")
+            lab(opt, a, w, c, b, stamps, detail, blocks, kt0, traced)
+            torch.cuda.synchronize()
+            dt = detail.cpu().numpy().astype("uint32").reshape(4, 2, 32).astype("int64")
+            bl = blocks.cpu().numpy().reshape(grid, 6)
+            print(f"-- v2 opt {opt} trace, detail K-tile {kt0}")
+            for s_, blk in enumerate(traced):
+                for g in range(2):
+                    x = dt[s_, g]
+                    per_tile = ((x[9] - x[8]) & 0xffffffff) / 64.0
+                    ph = []
+                    for i in range(2):
+                        t0, tl, tb, tm = (int(v) for v in x[i * 4:i * 4 + 4])
+                        nxt = int(x[4]) if i == 0 else int(x[10])
+                        ph.append(f"{'XY'[i]}: lds+wait {tl - t0:4d} b1 {tb - tl:4d} mfma {tm - tb:4d} b2 {(nxt - tm) & 0xffffffff:4d}")
+                    print(f"   block {blk:4d} group {g}: mean cycles per K-tile (tiles 8..72) {per_tile:7.1f} | " + " | ".join(ph))
+            rt0, rt1, mt0, mt1, mt2 = bl[:, 0], bl[:, 1], bl[:, 2], bl[:, 3], bl[:, 4]
+            dur = (rt1 - rt0) / 100.0
+            clk = (mt2 - mt0) / dur / 1e3
+            print(f"   workgroup us: median {np.median(dur):.1f} min {dur.min():.1f} max {dur.max():.1f}; clock GHz {np.median(clk):.3f}; "
+                  f"epilogue cycles median {np.median(mt2 - mt1):.0f} (first round {np.median((mt2 - mt1)[:256]):.0f}, later "
+                  f"{np.median((mt2 - mt1)[256:]):.0f}); kernel span {(rt1.max() - rt0.min()) / 100.0:.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["bench", "trace"]
+    if "parity" in what:
+        epilogue_parity()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     if "bench" in what:
         json.dump(bench(), open(os.path.join(ROOT, "gpurun_out", "gemm_lab_bench.json"), "w"), indent=1)
+    if "trace2" in what:
+        trace_v2()
     if "trace" in what:
         r = [trace(1), trace(9)]
         json.dump(r, open(os.path.join(ROOT, "gpurun_out", "gemm_lab_trace.json"), "w"))

@@ -308,6 +308,344 @@ __global__ __launch_bounds__(lab::THREADS, 2) void lab_gemm8(GemmParams p, lab::
   }
 }
 
+
+// =====================================================================================================================
+// v2: 16 MFMAs per segment (2 phases per K-tile), 3 A buffers + 2 W buffers (160 KiB), buffer_load...lds staging with the
+// K offset in an SGPR, ONE counted wait per K-tile, epilogue through LDS (row-contiguous 16-byte global accesses).
+//   interval 4t+0: g0 LDS X(t)   [W n0,n1 + A m0: 16 reads]     g1 MFMA Y(t-1)
+//   interval 4t+1: g0 MFMA X(t)  (+ stage A0,A1 of tile t+2)    g1 LDS X(t)
+//   interval 4t+2: g0 LDS Y(t)   [A m1: 8 reads, vmcnt(4)]      g1 MFMA X(t)
+//   interval 4t+3: g0 MFMA Y(t)  (+ stage W0,W1 of tile t+2)    g1 LDS Y(t)
+// A(t+2) goes to A buffer (t+2)%3 (last read in Y(t-1)), W(t+2) to W buffer t&1 (last read in X(t)).
+namespace v2 {
+constexpr int HALF_BYTES = 16384;
+constexpr int A_OFF = 0;                 // 3 buffers x 2 halves
+constexpr int W_OFF = 6 * HALF_BYTES;    // 2 buffers x 2 halves
+constexpr int TILE_LDS = 10 * HALF_BYTES;  // 160 KiB
+enum { V_TRACE = 1, V_OLD_EPI = 2 };
+}  // namespace v2
+
+// Epilogue through LDS.  Register layout (lane owns row m, 4 consecutive n per quad) -> wave-private 128 x 128-byte
+// image (16-byte chunk c of row r at chunk c ^ (r & 7), its 8-byte halves swapped when (r >> 3) & 1: conflict-free
+// ds_write_b64 and ds_read_b128) -> every lane reads 16 contiguous bytes of a row: residual loads and output stores are
+// whole 128-byte lines per 8 lanes.  Rounding chain as epilogue_quad: the value staged is t = bf16(...*gate), the
+// residual is added in f32 afterwards.
+template <bool F16>
+__device__ __forceinline__ void store_tile_lds(const GemmParams& p, int m_base, int n_base, int lane, int wave,
+                                               f32x16 (&acc)[4][2], char* smem) {
+  typedef Mfma32<F16> T;
+  const int l31 = lane & 31, g = lane >> 5;
+  char* img = smem + wave * 16384;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int row = mi * 32 + l31;
+    const int m = m_base + row;
+    const uint16_t* gp = nullptr;
+    if (p.gate) gp = p.gate + (size_t)((p.row_offset + min(m, p.M - 1)) / p.rows_per_frame) * p.gate_stride;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = n_base + ni * 32 + rq * 8 + g * 4;
+        const int nc = min(n, p.N - 4);
+        float v[4] = {acc[mi][ni][rq * 4 + 0], acc[mi][ni][rq * 4 + 1], acc[mi][ni][rq * 4 + 2], acc[mi][ni][rq * 4 + 3]};
+        if (p.bias) {
+          u32x2 b = *(const u32x2*)(p.bias + nc);
+          v[0] += T::to_f32(b[0] & 0xffff);
+          v[1] += T::to_f32(b[0] >> 16);
+          v[2] += T::to_f32(b[1] & 0xffff);
+          v[3] += T::to_f32(b[1] >> 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = T::round(v[i]);
+        if (p.act == 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = T::round(gelu_tanh(v[i]));
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = T::round(silu(v[i]));
+        }
+        if (p.gate) {
+          u32x2 gg = *(const u32x2*)(gp + nc);
+          v[0] = T::round(v[0] * T::to_f32(gg[0] & 0xffff));
+          v[1] = T::round(v[1] * T::to_f32(gg[0] >> 16));
+          v[2] = T::round(v[2] * T::to_f32(gg[1] & 0xffff));
+          v[3] = T::round(v[3] * T::to_f32(gg[1] >> 16));
+        }
+        u32x2 o;
+        o[0] = (uint32_t)T::from_f32(v[0]) | ((uint32_t)T::from_f32(v[1]) << 16);
+        o[1] = (uint32_t)T::from_f32(v[2]) | ((uint32_t)T::from_f32(v[3]) << 16);
+        const int chunk = (ni * 4 + rq) ^ (row & 7);
+        const int half = g ^ ((row >> 3) & 1);
+        *(u32x2*)(img + row * 128 + chunk * 16 + half * 8) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  const int rsub = lane >> 3, c = lane & 7;
+  const int n = n_base + c * 8;
+  const bool n_ok = n < p.N;
+  u32x4 res[16];
+  if (p.residual) {
+#pragma unroll
+    for (int ps = 0; ps < 16; ++ps) {
+      const int m = min(m_base + ps * 8 + rsub, p.M - 1);
+      res[ps] = *(const u32x4*)(p.residual + (size_t)m * p.ldr + min(n, p.N - 8));
+    }
+  }
+#pragma unroll
+  for (int ps = 0; ps < 16; ++ps) {
+    const int row = ps * 8 + rsub;
+    const int m = m_base + row;
+    u32x4 t = *(const u32x4*)(img + row * 128 + ((c ^ (row & 7)) << 4));
+    if ((row >> 3) & 1) t = u32x4{t[2], t[3], t[0], t[1]};
+    if (p.residual) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a0 = T::to_f32(t[i] & 0xffff) + T::to_f32(res[ps][i] & 0xffff);
+        const float a1 = T::to_f32(t[i] >> 16) + T::to_f32(res[ps][i] >> 16);
+        t[i] = (uint32_t)T::from_f32(a0) | ((uint32_t)T::from_f32(a1) << 16);
+      }
+    }
+    if (m < p.M && n_ok) *(u32x4*)(p.C + (size_t)m * p.ldc + n) = t;
+  }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(512, 2) void lab_gemm_v2(GemmParams p, lab::LabArgs la) {
+  using namespace v2;
+  constexpr bool TRACE = OPT & V_TRACE;
+  constexpr bool OLD_EPI = OPT & V_OLD_EPI;
+  typedef TileCfg<256, 256, 64, 2, 4> Cfg;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  unsigned long long rt0 = 0, mt0 = 0;
+  if (TRACE) {
+    rt0 = __builtin_amdgcn_s_memrealtime();
+    mt0 = __builtin_readcyclecounter();
+  }
+  const int kt_begin = 0, kt_end = p.K / 64;
+  const int tile_id = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = tile_id / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = tile_id - group * per_group;
+  const int m0 = (first_m + in_group % gm) * 256;
+  const int n0 = (in_group / gm) * 256;
+
+  uint32_t src_off[4][2];  // [A0, A1, W0, W1][piece] BYTE offsets at k = 0
+  {
+    const int rsub = lane >> 3, cpos = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 64 + wave * 8 + rsub;
+      const int ch = (cpos ^ ((row >> 1) & 7)) * 8;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int gm_row = min(m0 + h * 128 + row, p.M - 1);
+        const int gn_row = min(n0 + h * 128 + row, p.N - 1);
+        src_off[h][j] = ((uint32_t)gm_row * (uint32_t)p.lda + ch) * 2u;
+        src_off[2 + h][j] = ((uint32_t)gn_row * (uint32_t)p.ldw + ch) * 2u;
+      }
+    }
+  }
+  __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  // slot of half h (0,1 = A0,A1; 2,3 = W0,W1) of K-tile kt; a3 = kt % 3
+  auto stage_piece = [&](int kt, int a3, int h, int j, auto chk) {
+    if (decltype(chk)::value && kt >= kt_end) return;
+    const int slot = h < 2 ? A_OFF + (a3 * 2 + h) * HALF_BYTES : W_OFF + ((kt & 1) * 2 + (h - 2)) * HALF_BYTES;
+    char* dst = smem + slot + (j * 64 + wave * 8) * 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(h < 2 ? rsrcA : rsrcW, (RTV_LDS void*)dst, 16, src_off[h][j], (unsigned)kt * 128u,
+                                             0, 0);
+  };
+
+  u32x4 af[2][4];
+  u32x4 bfr[2][4];
+  const int b_row0 = (wc & 1) * 64;
+  auto read_a = [&](int a3, int mq) {
+    const char* s = smem + A_OFF + (a3 * 2 + wr) * HALF_BYTES;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int row = mq * 64 + mb * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[mb][ks] = *(const u32x4*)(s + row * 128 + (((ks * 2 + g) ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+  auto read_w = [&](int wb) {
+    const char* s = smem + W_OFF + (wb * 2 + (wc >> 1)) * HALF_BYTES;
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+      const int row = b_row0 + nq * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[nq][ks] = *(const u32x4*)(s + row * 128 + (((ks * 2 + g) ^ ((row >> 1) & 7)) << 4));
+    }
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // MFMA segment: 16 MFMA on the 64 x 64 half (mq; n0, n1) + 4 DMA pieces (halves h0, h0 + 1 of tile st_kt)
+  auto mma_half = [&](int mq, int st_kt, int st_a3, int h0, auto chk) {
+    __builtin_amdgcn_s_setprio(1);
+    int n = 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          acc[mq * 2 + mb][nq] = Mfma32<false>::run(bfr[nq][ks], af[mb][ks], acc[mq * 2 + mb][nq]);
+          ++n;
+          if ((n & 3) == 2) {
+            L_FENCE();
+            stage_piece(st_kt, st_a3, h0 + (n >> 3), (n >> 2) & 1, chk);
+            L_FENCE();
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- prologue: tiles 0 and 1 complete
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    stage_piece(kt_begin + t, t, 2, 0, std::true_type{});
+    stage_piece(kt_begin + t, t, 2, 1, std::true_type{});
+    stage_piece(kt_begin + t, t, 3, 0, std::true_type{});
+    stage_piece(kt_begin + t, t, 3, 1, std::true_type{});
+    stage_piece(kt_begin + t, t, 0, 0, std::true_type{});
+    stage_piece(kt_begin + t, t, 0, 1, std::true_type{});
+    stage_piece(kt_begin + t, t, 1, 0, std::true_type{});
+    stage_piece(kt_begin + t, t, 1, 1, std::true_type{});
+  }
+  if (kt_begin + 1 < kt_end) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  L_BARRIER();
+  if (wr == 1) L_BARRIER();
+
+  unsigned* tstamps = (unsigned*)(smem + TILE_LDS - 2048) + wr * 256;  // TRACE only: overlays the tail of W buffer 1, dumped late
+  unsigned tstamp_reg[0 + 1];
+  (void)tstamps;
+  (void)tstamp_reg;
+  unsigned dtl[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dtl[i][j] = 0;
+  unsigned tile_t0 = 0, tile_t1 = 0, tile_tn = 0;
+#define V_STAMP(ph, idx)                                       \
+  do {                                                         \
+    if (TRACE && detail) {                                     \
+      L_FENCE();                                               \
+      dtl[ph][idx] = (unsigned)__builtin_readcyclecounter();   \
+      L_FENCE();                                               \
+    }                                                          \
+  } while (0)
+
+  int a3 = 0;  // kt % 3
+  auto k_tile = [&](const int kt, auto chk) {
+    constexpr bool CHK = decltype(chk)::value;
+    const bool detail = TRACE && kt == la.kt0;
+    if (TRACE && (kt == 8 || kt == 72 || kt == la.kt0 + 1)) {   // average K-tile time over 64 tiles, no per-tile work
+      L_FENCE();
+      const unsigned t = (unsigned)__builtin_readcyclecounter();
+      if (kt == 8) tile_t0 = t;
+      if (kt == 72) tile_t1 = t;
+      if (kt == la.kt0 + 1) tile_tn = t;
+      L_FENCE();
+    }
+    const int a3n = a3 == 0 ? 2 : a3 - 1;   // (kt + 2) % 3
+    // ---------------- phase X
+    V_STAMP(0, 0);
+    read_w(kt & 1);
+    read_a(a3, 0);
+    L_LDS_DONE();
+    V_STAMP(0, 1);
+    L_BARRIER();
+    V_STAMP(0, 2);
+    mma_half(0, kt + 2, a3n, 0, chk);
+    V_STAMP(0, 3);
+    L_BARRIER();
+    // ---------------- phase Y
+    V_STAMP(1, 0);
+    read_a(a3, 1);
+    if (!CHK || kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    L_LDS_DONE();
+    V_STAMP(1, 1);
+    L_BARRIER();
+    V_STAMP(1, 2);
+    mma_half(1, kt + 2, a3n, 2, chk);
+    V_STAMP(1, 3);
+    L_BARRIER();
+    a3 = a3 == 2 ? 0 : a3 + 1;
+  };
+  int kt = kt_begin;
+  for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});
+  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});
+  if (wr == 0) L_BARRIER();
+
+  unsigned long long mt1 = 0;
+  if (TRACE) mt1 = __builtin_readcyclecounter();
+  if (OLD_EPI) store_tile<false, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
+  else store_tile_lds<false>(p, m0 + wr * 128, n0 + wc * 64, lane, wave, acc, smem);
+
+  if (TRACE) {
+    int slot = -1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (la.traced[i] == (int)blockIdx.x) slot = i;
+    if (slot >= 0 && wc == 0 && lane < 12) {
+      unsigned v = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (lane == i * 4 + j) v = dtl[i][j];
+      if (lane == 8) v = tile_t0;
+      if (lane == 9) v = tile_t1;
+      if (lane == 10) v = tile_tn;
+      la.detail[(slot * 2 + wr) * 32 + lane] = v;
+    }
+    if (tid == 0) {
+      const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long mt2 = __builtin_readcyclecounter();
+      const unsigned hw = __builtin_amdgcn_s_getreg(63492);
+      const unsigned xcc = __builtin_amdgcn_s_getreg(63508);
+      unsigned long long* b = la.blocks + (size_t)blockIdx.x * 6;
+      b[0] = rt0;
+      b[1] = rt1;
+      b[2] = mt0;
+      b[3] = mt1;
+      b[4] = mt2;
+      b[5] = ((unsigned long long)xcc << 32) | hw;
+    }
+  }
+}
+
+template <int OPT>
+static int launch_v2(GemmParams p, lab::LabArgs la, hipStream_t stream) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = (p.N + 255) / 256;
+  auto kern = lab_gemm_v2<OPT>;
+  const int lds = v2::TILE_LDS;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -2;
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(512), lds, stream, p, la);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 template <int OPT>
 static int launch(GemmParams p, lab::LabArgs la, hipStream_t stream) {
   p.tiles_m = (p.M + 255) / 256;
@@ -356,7 +694,41 @@ extern "C" int lab_gemm(int opt, const void* A, const void* W, void* C, const vo
   case o:       \
     return launch<o>(p, la, s);
     CASE(0) CASE(1) CASE(2) CASE(4) CASE(8) CASE(10) CASE(16) CASE(32) CASE(40) CASE(9)
+    case 100:
+      return launch_v2<0>(p, la, s);
+    case 101:
+      return launch_v2<1>(p, la, s);
+    case 102:
+      return launch_v2<2>(p, la, s);
+    case 103:
+      return launch_v2<3>(p, la, s);
     default:
       return -1;
   }
+}
+
+// v2 with the full fused epilogue (activation / gate / residual) for the epilogue parity check
+extern "C" int lab_gemm_v2_epi(const void* A, const void* W, void* C, const void* bias, int act, const void* gate,
+                               int gate_stride, int rows_per_frame, const void* residual, int M, int N, int K, int old_epi,
+                               void* stream) {
+  GemmParams p;
+  p.A = (const uint16_t*)A;
+  p.W = (const uint16_t*)W;
+  p.C = (uint16_t*)C;
+  p.lda = K;
+  p.ldw = K;
+  p.ldc = N;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.bias = (const uint16_t*)bias;
+  p.act = act;
+  p.gate = (const uint16_t*)gate;
+  p.gate_stride = gate_stride;
+  p.rows_per_frame = rows_per_frame;
+  p.row_offset = 0;
+  p.residual = (const uint16_t*)residual;
+  p.ldr = N;
+  lab::LabArgs la{};
+  return old_epi ? launch_v2<2>(p, la, (hipStream_t)stream) : launch_v2<0>(p, la, (hipStream_t)stream);
 }

@@ -81,7 +81,7 @@ def _gemm_ref(a, w, bias, act, gate, rows_per_frame, residual):
     return y
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 52])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(4680, 1536, 1536), (200, 64, 256), (3, 1536, 256), (585, 4608, 1536),
                                    (4680, 256, 64)])
 def test_gemm_bias(ops, M, N, K, cfg):
@@ -126,10 +126,10 @@ def test_gemm_fp16(ops):
     assert rel_l2(out, ref) <= 1e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 5, 7, 52])
+@pytest.mark.parametrize("cfg", [0, 5])
 @pytest.mark.parametrize("M,N,K", [(4680, 5120, 1024), (4680, 13824, 512), (2400, 7680, 2048)])
 def test_gemm_split_k_tail_round(ops, M, N, K, cfg):
-    """tile_cfg 5 / 7: the tiles of the last partial round are split along K over several workgroups and reduced in-launch
+    """tile_cfg 5: the tiles of the last partial round are split along K over several workgroups and reduced in-launch
     (agent-scope release/acquire + arrival counter).  Repeated launches reuse the workspace."""
     a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
     ref = _gemm_ref(a, w, b, 1, None, 0, None)
@@ -137,6 +137,46 @@ def test_gemm_split_k_tail_round(ops, M, N, K, cfg):
         out = ops.gemm(a, w, bias=b, act=1, tile_cfg=cfg)
         assert rel_l2(out, ref) <= 4e-3
         assert max_abs(out, ref) <= 0.05 * float(ref.float().abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("M,N,K", [(4680, 1536, 512), (777, 264, 64), (130, 5128, 128), (1560, 512, 192)])
+def test_gemm_epilogue_through_lds_all_fusions(ops, M, N, K, cfg):
+    """Every fused epilogue (bias / GELU / SiLU / per-frame gate + residual in place / residual only) through the LDS-staged
+    coalesced store path of every tile config, ragged M and N edges, K of 1..3 K-tiles (pipeline prologue / tail), and the
+    narrow fallback (output rows not 16-byte aligned: a column slice of a wider buffer).  Repeated launches must be
+    bit-identical (race screen of the DMA / barrier schedule)."""
+    fs = (M + 2) // 3
+    a, w, b = _randn(M, K, seed=7), _randn(N, K, seed=8, scale=K ** -0.5), _randn(N, seed=9, scale=0.1)
+    emod = _randn(3, 6, N, seed=10)
+    x = _randn(M, N, seed=11)
+    for act, gate, res in [(0, False, False), (1, False, False), (2, False, True), (0, True, True)]:
+        ref = _gemm_ref(a, w, b, act, emod[:, 2] if gate else None, fs, x if res else None)
+        outs = []
+        for rep in range(3):
+            xin = x.clone()
+            out = ops.gemm(a, w, bias=b, act=act, gate=emod[0, 2] if gate else None, gate_stride=6 * N,
+                           rows_per_frame=fs if gate else 0, residual=xin if res else None, out=xin if res else None,
+                           tile_cfg=cfg)
+            outs.append(out.clone())
+        assert rel_l2(outs[0], ref) <= 4e-3, (act, gate, res)
+        assert max_abs(outs[0], ref) <= 0.05 * float(ref.float().abs().max()) + 1e-3
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        # narrow path: ldc = N + 4 keeps 8-byte but not 16-byte row alignment -> same values through the direct store
+        wide = torch.zeros(M, N + 4, dtype=torch.bfloat16, device=DEV)
+        narrow = ops.gemm(a, w, bias=b, act=act, gate=emod[0, 2] if gate else None, gate_stride=6 * N,
+                          rows_per_frame=fs if gate else 0, residual=x if res else None, out=wide[:, :N], tile_cfg=cfg)
+        assert torch.equal(narrow, outs[0]) and float(wide[:, N:].abs().max()) == 0
+
+
+def test_gemm_fp16_epilogue_large_tile(ops):
+    """fp16 operands through the 256x256 kernel (tile_cfg 4) and its LDS epilogue with a fused residual (VAE usage)."""
+    M, N, K = 1000, 384, 384
+    a, w = _randn(M, K, seed=1, dtype=torch.float16), _randn(N, K, seed=2, dtype=torch.float16, scale=K ** -0.5)
+    b, r = _randn(N, seed=3, dtype=torch.float16, scale=0.1), _randn(M, N, seed=4, dtype=torch.float16)
+    ref = ((a.float() @ w.float().t() + b.float()).half().float() + r.float()).half()
+    for cfg in (1, 4):
+        assert rel_l2(ops.gemm(a, w, bias=b, residual=r, tile_cfg=cfg), ref) <= 1e-3
 
 
 def test_gemm_rejects_bad_arguments(ops):
@@ -571,7 +611,7 @@ def test_qk_norm_rope_cache_ring_write(ops):
     rows = 400
     base = _randn(rows, 2, H, 128, seed=4)
     plain, ring = base.clone(), base.clone()
-    row0, lo, size, shift = 150, 40, 300, 233        # rows [150, 270) wrap: 40 + (110 + 233 .. ) % 300
+    row0, lo, size, shift = 150, 40, 300, 100        # rows [150, 270): 40 + ((110 .. 229) + 100) % 300 wraps after 90 rows
     q0 = ops.qk_norm_rope_cache(qkv, plain[:, 0], plain[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5)
     q1 = ops.qk_norm_rope_cache(qkv, ring[:, 0], ring[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5, ring=(lo, size, shift))
     assert torch.equal(q0, q1)
