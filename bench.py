@@ -37,26 +37,32 @@ def gemm_algorithmic_bytes(mc, M=4680):
 
 
 def measured_traffic(model):
-    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
-    (scripts/profile_bench.sh over this same command; FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_traffic_{model}.json")
-    try:
-        with open(path) as f:
-            g = json.load(f)["classes"]["gemm"]
-        return g["hbm_bytes_per_launch"], os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))
-    except (OSError, KeyError, ValueError):
-        return None, None
+    """HBM-side bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes over the six
+    projection shapes of a layer (scripts/profile_gemm_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md, separate
+    --pmc passes).  rocprofv3 --pmc cannot run inside this process, so the committed summary of the newest round is read;
+    its sample size and file travel in the JSON line."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rnd in ("r02", "r01"):
+        path = os.path.join(root, "profiles", f"{rnd}_traffic_{model}.json")
+        try:
+            with open(path) as f:
+                g = json.load(f)["classes"]["gemm"]
+            return g["hbm_bytes_per_launch"], os.path.relpath(path, root), g.get("launches_sampled")
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None, None
 
 
-def cpu_baseline(model_cfg, seconds_budget=30.0):
-    """The CPU oracle (port of the reference's eager path) timed on this host's cores on a bounded sample:
-    ONE DiT layer of the benchmarked width at the real token counts (M=4680 queries, 9360 cached keys),
-    extrapolated to a block (40 layers x (4 denoise + 0.88 recompute-equivalent) forwards), DiT only."""
+def cpu_baseline(model_cfg, with_vae=True):
+    """The CPU oracle (a port of the reference's eager path: oracle/wan_oracle.py, oracle/vae_oracle.py) timed on this host's
+    cores on a bounded sample of the benchmarked block: ONE DiT layer of the benchmarked width at the real token counts
+    (M = 4680 queries, 9360 cached keys; run twice, the second - warm - run is the sample) extrapolated to the block's
+    (4 denoise + 0.88 recompute-equivalent) x L layer-forwards, plus ONE latent frame of the streaming VAE decode at
+    480 x 832 on warm caches (fp32; 4 of the block's 12 pixel frames) extrapolated x3."""
     from oracle import wan_oracle as wo
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     d, ffn, H = model_cfg["dim"], model_cfg["ffn_dim"], model_cfg["num_heads"]
-    cfg = dict(dim=d, ffn_dim=ffn, num_heads=H, num_layers=1)
     g = torch.Generator().manual_seed(0)
     w = {}
     for a in ("self_attn", "cross_attn"):
@@ -74,22 +80,38 @@ def cpu_baseline(model_cfg, seconds_budget=30.0):
     x = torch.randn(1, 4680, d, generator=g).to(torch.bfloat16)
     e = torch.randn(1, 3, 6, d, generator=g).to(torch.bfloat16) * 0.1
     ctx = torch.randn(1, 512, d, generator=g).to(torch.bfloat16)
-    kv = wo.initialize_kv_cache(1, 1, 9360, H, 128, torch.bfloat16)[0]
-    kv["k"][:, :4680].normal_(generator=g)
-    kv["v"][:, :4680].normal_(generator=g)
-    kv["global_end_index"] = kv["local_end_index"] = 4680
-    ca = wo.initialize_crossattn_cache(1, 1, H, 128, torch.bfloat16)[0]
     freqs = wo.rope_table(128)
-    t0 = time.time()
-    with torch.inference_mode():
-        wo.attention_block(w, "blocks.0", x, e, (3, 30, 52), freqs, ctx, H, kv, ca, 4680, False)
-    t_layer = time.time() - t0
+    t_layer = None
+    for _ in range(2):   # the second (warm: thread pool, allocator, weights paged in) iteration is the sample
+        kv = wo.initialize_kv_cache(1, 1, 9360, H, 128, torch.bfloat16)[0]
+        kv["k"][:, :4680].normal_(generator=g)
+        kv["v"][:, :4680].normal_(generator=g)
+        kv["global_end_index"] = kv["local_end_index"] = 4680
+        ca = wo.initialize_crossattn_cache(1, 1, H, 128, torch.bfloat16)[0]
+        t0 = time.time()
+        with torch.inference_mode():
+            wo.attention_block(w, "blocks.0", x, e, (3, 30, 52), freqs, ctx, H, kv, ca, 4680, False)
+        t_layer = time.time() - t0
+    del w, x, kv
     L = model_cfg["num_layers"]
-    t_block = t_layer * L * 4.88
+    t_dit = t_layer * L * 4.88
+    t_vae = None
+    if with_vae:
+        from oracle import vae_oracle as vo
+        wv = vo.make_vae_weights(seed=0)
+        cache = [None] * 55
+        with torch.inference_mode():
+            _, cache = vo.decoder_wrapper_forward(wv, torch.randn(1, 1, 16, 60, 104, generator=g), cache)   # fills the caches
+            t0 = time.time()
+            vo.decoder_wrapper_forward(wv, torch.randn(1, 1, 16, 60, 104, generator=g), cache)               # steady state: 4 frames
+            t_vae = (time.time() - t0) * 3
+    t_block = t_dit + (t_vae or 0.0)
     return {"value": 12.0 / t_block, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"1 DiT layer at the benchmarked width (d={d}, ffn={ffn}, H={H}), M=4680 query tokens, 9360 cached "
-                      f"keys, bf16 eager oracle, {t_layer:.2f} s measured once; extrapolated x{L} layers x 4.88 forwards "
-                      f"per 12-frame block, DiT only (VAE excluded)"}
+            "sample": f"DiT: 1 layer at the benchmarked width (d={d}, ffn={ffn}, H={H}), M=4680 query tokens, 9360 cached keys, "
+                      f"bf16 eager oracle, second of two runs {t_layer:.2f} s, extrapolated x{L} layers x 4.88 forwards per 12-frame "
+                      f"block = {t_dit:.0f} s" + (f"; VAE: 1 latent frame (4 of 12 pixel frames) of the streaming decode at 480x832 "
+                                                  f"on warm caches, fp32 eager oracle, {t_vae / 3:.2f} s, x3 = {t_vae:.0f} s"
+                                                  if t_vae is not None else "; VAE excluded")}
 
 
 def main():
@@ -102,9 +124,9 @@ def main():
     ap.add_argument("--denoising-steps", type=int, default=4)
     ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-classes", default="gemm",
-                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm' (the roofline kernel, "
-                         "default), 'all' (diagnostic: every launch, costs a few %% of throughput) or 'none'")
+    ap.add_argument("--profile-classes", default="gemm,attn",
+                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm,attn' (the roofline kernel and "
+                         "the attention kernel, default), 'all' (diagnostic: every launch, costs a few %% of throughput) or 'none'")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
                          "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
@@ -119,6 +141,9 @@ def main():
     ap.add_argument("--cp-exchange", default="auto", choices=["auto", "heads", "rows"],
                     help="context-parallel exchange around self-attention: heads = all-to-all pair (head-sharded KV cache), "
                          "rows = K/V all-gather (replicated cache); auto = heads when the head count divides")
+    ap.add_argument("--no-cp-overlap", action="store_true",
+                    help="A/B: complete every context-parallel collective before the next kernel is issued (default: the "
+                         "q all-to-all runs under the k|v projection / the K/V all-gather under the q projection)")
     ap.add_argument("--simulate-cp", type=int, default=0,
                     help="diagnostic (INVALID as a result): run all shards of an N-way context-parallel forward in lockstep "
                          "on this one GPU (no collectives, --no-vae implied); kernel_ms_per_block / N = one rank's compute")
@@ -127,14 +152,30 @@ def main():
                          "replicas = one independent stream per GPU (weak scaling, no collective)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    shared_gpu = os.environ.get("RTV_BENCH_SHARED_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU of this node
+        if torch.cuda.device_count() < args.gpus and not shared_gpu:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {torch.cuda.device_count()} GPU(s) visible")
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.gpus != world:
+        # a line that claims N GPUs must have run on N ranks: never fall back to fewer silently
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if world > 1 and torch.cuda.device_count() < world and not shared_gpu:
+        raise SystemExit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible")
     # RTV_BENCH_SHARED_GPU=1 (test rigs with fewer GPUs than ranks): all ranks share cuda:0 and the collectives run over
     # gloo staged through the host -- exercises the multi-rank code path, the numbers mean nothing
-    shared_gpu = os.environ.get("RTV_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -145,8 +186,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from realtime_video_amd import ops
     from realtime_video_amd.causal_model import CausalWanModel
@@ -170,7 +209,7 @@ def main():
     use_cp = world > 1 and args.parallel == "cp"
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
-        model.context_parallel = ContextParallel(exchange=args.cp_exchange)
+        model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap)
     if args.simulate_cp > 1:
         from realtime_video_amd.parallel import SimulatedContextParallel
         model.context_parallel = SimulatedContextParallel(args.simulate_cp, args.cp_exchange)
@@ -271,7 +310,7 @@ def main():
     gm = prof["gemm"]
     achieved = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     fwd_per_block = args.denoising_steps + 1
-    traffic, traffic_src = measured_traffic(args.model) if world == 1 and not args.fp8 else (None, None)
+    traffic, traffic_src, traffic_n = measured_traffic(args.model) if world == 1 and not args.fp8 else (None, None, None)
     result = {
         "metric": "frames/sec at 832x480, 4-step 14B T2V (per-step DiT latency in config)",
         "value": total_frames / elapsed,
@@ -322,6 +361,7 @@ def main():
             "frac": achieved / (MFMA_PEAK_TFLOPS * (2.0 if args.fp8 else 1.0)),
             "traffic": traffic,
             "traffic_source": traffic_src,
+            "traffic_launches_sampled": traffic_n,
             "algorithmic_bytes_per_launch": None if args.fp8 else gemm_algorithmic_bytes(mc),
             "frac_of_sustained_mfma": achieved / (MFMA_SUSTAINED_FP8_TFLOPS if args.fp8 else MFMA_SUSTAINED_TFLOPS),
             "launches": gm["launches"],
@@ -331,7 +371,7 @@ def main():
         },
     }
     if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(mc)
+        result["cpu_baseline"] = cpu_baseline(mc, with_vae=not args.no_vae)
     print(json.dumps(result))
 
 

@@ -232,6 +232,17 @@ int rtv_dit_layer_qkv(const rtv_dit_config* cfg, const rtv_dit_weights* w, const
                       void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 int rtv_dit_layer_rest(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer,
                        void* workspace, size_t workspace_bytes, rtv_stream_t stream);
+/* rtv_dit_layer_qkv in pieces, so that the host can start the exchange of one projection and let it run UNDER the other
+ * projection (north_star: collectives overlapped with compute; design hint xdit_context_parallel.py:131-142):
+ *   parts = RTV_PROJ_LN (LayerNorm + modulation of the layer input, needed once) | RTV_PROJ_Q (q columns of the fused QKV
+ *   weight -> RMSNorm + RoPE -> local q, or q_send) | RTV_PROJ_KV (k, v columns -> RMSNorm(k) + RoPE(k) -> cache rows, or
+ *   kv_send).  q_send / kv_send: the head-parallel exchange buffers of rtv_dit_layer_qkv_hp (world > 1), or NULL for the
+ *   K/V-all-gather exchange.  Typical: [LN|Q] -> all-to-all(q) async -> [KV] -> all-to-all(k|v) -> wait;  or, with the
+ *   all-gather exchange, [LN|KV] -> all-gather(K/V rows) async -> [Q] -> wait. */
+enum { RTV_PROJ_LN = 1, RTV_PROJ_Q = 2, RTV_PROJ_KV = 4 };
+int rtv_dit_layer_proj(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, int layer,
+                       int parts, int world, void* q_send, void* kv_send,
+                       void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 int rtv_dit_head(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* step, void* head_rows,
                  void* workspace, size_t workspace_bytes, rtv_stream_t stream);
 int rtv_dit_finish(const rtv_dit_config* cfg, const rtv_dit_step* step, const void* head_rows, rtv_stream_t stream);

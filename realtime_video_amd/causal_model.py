@@ -70,6 +70,8 @@ _P3 = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step)]
 _lib.EXTRA_SIGNATURES["rtv_dit_begin"] = _P3 + [c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_qkv"] = _P3 + [ctypes.c_int, c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_rest"] = _P3 + [ctypes.c_int, c_vp, ctypes.c_size_t, c_vp]
+_lib.EXTRA_SIGNATURES["rtv_dit_layer_proj"] = _P3 + [ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
+PROJ_LN, PROJ_Q, PROJ_KV = 1, 2, 4
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_qkv_hp"] = _P3 + [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_attn_hp"] = _P3 + [ctypes.c_int, ctypes.c_int, c_vp, c_vp, c_vp, ctypes.c_size_t, c_vp]
 _lib.EXTRA_SIGNATURES["rtv_dit_layer_rest_hp"] = _P3 + [ctypes.c_int, ctypes.c_int, c_vp, c_vp, ctypes.c_size_t, c_vp]
@@ -538,18 +540,32 @@ class CausalWanModel:
                 parts = [make(shard_rows(M, W, r), i) for i, r in enumerate(cp.local_ranks())]
             for st, wsa in parts:
                 _lib.call("rtv_dit_begin", cfg_p, w_p, ctypes.byref(st), *wsa)
+            # Per layer the projection runs in two pieces with the exchange of the first one in flight under the second
+            # (rtv_dit_layer_proj; the collective runs on the process group's communication stream):
+            #   rows  exchange: [LN | K,V] -> all-gather of the new K/V rows (async) -> [Q] -> wait -> attention ...
+            #   heads exchange: [LN | Q]   -> all-to-all(q) (async) -> [K,V] -> all-to-all(k|v) (async) -> wait both -> attention
+            null = c_vp(0)
             for l in range(L):
                 if not heads:
                     for st, wsa in parts:
-                        _lib.call("rtv_dit_layer_qkv", cfg_p, w_p, ctypes.byref(st), l, *wsa)
-                    cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, 0, null, null, *wsa)
+                    pend = cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
+                    for st, wsa in parts:
+                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_Q, 0, null, null, *wsa)
+                    pend.wait()
                     for st, wsa in parts:
                         _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
                     continue
                 for (st, wsa), (_, b) in zip(parts, bufs):
-                    _lib.call("rtv_dit_layer_qkv_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_send"].data_ptr()),
+                    _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_Q, W,
+                              c_vp(b["q_send"].data_ptr()), null, *wsa)
+                pend_q = cp.exchange_q(bufs, async_op=True)
+                for (st, wsa), (_, b) in zip(parts, bufs):
+                    _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_KV, W, null,
                               c_vp(b["kv_send"].data_ptr()), *wsa)
-                cp.exchange_qkv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                pend_kv = cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
+                pend_q.wait()
+                pend_kv.wait()
                 for (st, wsa), (_, b) in zip(parts, bufs):
                     _lib.call("rtv_dit_layer_attn_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_all"].data_ptr()),
                               c_vp(b["o_all"].data_ptr()), *wsa)

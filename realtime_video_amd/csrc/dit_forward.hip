@@ -202,20 +202,56 @@ static int dit_begin(Ctx& c) {
   return 0;
 }
 
-// ---- layer, part 1: LN+modulate -> QKV -> RMSNorm(q,k)+RoPE -> local K/V rows into the cache
-static int dit_layer_qkv(Ctx& c, int l) {
+static int hp_check(Ctx& c, int world);
+
+// ---- layer, part 1: LN+modulate -> QKV -> RMSNorm(q,k)+RoPE -> local K/V rows into the cache (or the exchange buffers).
+// `parts` selects what this call does, so that the host can put a collective between the two projections and let it run
+// under the other one (RTV_PROJ_*): LN (the shared input of both), Q (columns [0, d) of the fused QKV weight), KV (columns
+// [d, 3d)).  q_send / kv_send non-null = head-parallel exchange buffers (see below), null = local q + cache rows.
+static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, void* kv_send) {
   const rtv_dit_layer_weights& lw = c.w->layers[l];
   const rtv_dit_step* st = c.st;
   DitBuffers& b = c.b;
   const int d = c.d;
+  if (!(parts & (RTV_PROJ_LN | RTV_PROJ_Q | RTV_PROJ_KV))) return set_error(-1, "dit: empty projection phase");
   const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;  // [F][6][d]: shift_sa, scale_sa, gate_sa, shift_ffn, scale_ffn, gate_ffn
-  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
-  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_QKV, b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
-  RTV_TRY(rtv_qk_norm_rope_cache_ring(b.qkv, b.q, st->kv_k[l], st->kv_v[l], st->kv_row_stride, st->cache_row0, c.rc, d, c.H,
-                                      c.cfg->eps, lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame,
-                                      c.r0, st->ring_lo, st->ring_size, st->ring_shift, c.stream));
-  return 0;
+  if (parts & RTV_PROJ_LN)
+    RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
+  const bool q = parts & RTV_PROJ_Q, kv = parts & RTV_PROJ_KV;
+  if (!q && !kv) return 0;
+  // the fused weight is [3d, d] row-major: a column range of the output is a row range of the weight
+  const int n0 = q ? 0 : d, nn = (q ? d : 0) + (kv ? 2 * d : 0);
+  const uint16_t* wq = (const uint16_t*)lw.qkv_w;
+  const uint16_t* bq = (const uint16_t*)lw.qkv_b;
+  const size_t welt = c.cfg->use_fp8 ? 1 : 2;   // fp8 weights are bytes
+  {
+    const void* wp = (const char*)lw.qkv_w + (size_t)n0 * d * welt;
+    (void)wq;
+    if (!c.cfg->use_fp8) {
+      RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, nn, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc,
+                       c.stream));
+    } else {
+      if (!c.w->fp8_scales) return set_error(-1, "dit: use_fp8 needs rtv_dit_weights.fp8_scales");
+      if (rtv_quantize_fp8(b.xn, d, c.rc, d, b.q8, d, b.fscale, b.fscale + 1, c.stream)) return -1;
+      RTV_TRY(rtv_gemm_fp8(b.q8, d, wp, d, b.fscale, c.w->fp8_scales[S_LAYER0 + S_PER_LAYER * l + S_QKV], b.qkv + n0, 3 * d, c.rc, nn, d,
+                           bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, c.stream));
+    }
+  }
+  const int rope_parts = (q ? 1 : 0) | (kv ? 2 : 0);
+  if (q_send || kv_send) {
+    RTV_TRY(hp_check(c, world));
+    const int gc = d / world;
+    if ((q && !q_send) || (kv && !kv_send)) return set_error(-1, "dit: exchange buffers required");
+    return qk_norm_rope_launch(b.qkv, q_send, kv_send, kv_send ? (void*)((uint16_t*)kv_send + gc) : nullptr, 2 * gc, 0, c.rc, d, c.H,
+                               c.cfg->eps, lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame, c.r0, gc,
+                               (int64_t)c.rc * gc, (int64_t)c.rc * 2 * gc, 0, 0, 0, rope_parts, c.stream);
+  }
+  return qk_norm_rope_launch(b.qkv, b.q, st->kv_k[l], st->kv_v[l], st->kv_row_stride, st->cache_row0, c.rc, d, c.H, c.cfg->eps,
+                             lw.norm_q_w, lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, st->start_frame, c.r0, 0, 0, 0, st->ring_lo,
+                             st->ring_size, st->ring_shift, rope_parts, c.stream);
 }
+
+static int dit_layer_qkv(Ctx& c, int l) { return dit_layer_proj(c, l, RTV_PROJ_LN | RTV_PROJ_Q | RTV_PROJ_KV, 0, nullptr, nullptr); }
 
 static int dit_after_attn(Ctx& c, int l);
 
@@ -301,16 +337,7 @@ static int hp_check(Ctx& c, int world) {
 }
 
 static int dit_layer_qkv_hp(Ctx& c, int l, int world, void* q_send, void* kv_send) {
-  RTV_TRY(hp_check(c, world));
-  const rtv_dit_layer_weights& lw = c.w->layers[l];
-  DitBuffers& b = c.b;
-  const int d = c.d, gc = d / world;
-  const uint16_t* em = b.emod + (size_t)l * c.F * 6 * d;
-  RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, c.rc, d, c.cfg->eps, em + 0 * d, em + 1 * d, 6 * d, c.fs, c.r0, nullptr, nullptr, c.stream));
-  RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_QKV, b.xn, d, lw.qkv_w, lw.qkv_b, b.qkv, c.rc, 3 * d, 0, nullptr, 0, 0, 0, nullptr, c.tc, c.stream));
-  return qk_norm_rope_launch(b.qkv, q_send, kv_send, (uint16_t*)kv_send + gc, 2 * gc, 0, c.rc, d, c.H, c.cfg->eps, lw.norm_q_w,
-                             lw.norm_k_w, c.w->rope_cs, c.F, c.gh, c.gw, c.st->start_frame, c.r0, gc, (int64_t)c.rc * gc,
-                             (int64_t)c.rc * 2 * gc, 0, 0, 0, c.stream);
+  return dit_layer_proj(c, l, RTV_PROJ_LN | RTV_PROJ_Q | RTV_PROJ_KV, world, q_send, kv_send);
 }
 
 static int dit_layer_attn_hp(Ctx& c, int l, int world, const void* q_all, void* o_all) {
@@ -357,6 +384,15 @@ extern "C" int rtv_dit_layer_qkv(const rtv_dit_config* cfg, const rtv_dit_weight
   RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
   if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
   return dit_layer_qkv(c, layer);
+}
+
+extern "C" int rtv_dit_layer_proj(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,
+                                  int parts, int world, void* q_send, void* kv_send, void* ws, size_t ws_bytes,
+                                  rtv_stream_t stream) {
+  Ctx c;
+  RTV_TRY(make_ctx(cfg, w, st, ws, ws_bytes, stream, &c));
+  if (layer < 0 || layer >= c.L) return set_error(-1, "dit: layer out of range");
+  return dit_layer_proj(c, layer, parts, world, q_send, kv_send);
 }
 
 extern "C" int rtv_dit_layer_rest(const rtv_dit_config* cfg, const rtv_dit_weights* w, const rtv_dit_step* st, int layer,

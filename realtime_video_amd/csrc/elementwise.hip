@@ -160,6 +160,7 @@ struct RopeArgs {
   // rolling cache as a ring: logical cache row r >= ring_lo lives at ring_lo + (r - ring_lo + ring_shift) % ring_size
   // (ring_size == 0: no ring, logical == physical); rows below ring_lo are the attention-sink rows and never move.
   int ring_lo, ring_size, ring_shift;
+  int parts;   // bit 0: process q, bit 1: process k and v (the split projection of the context-parallel overlap; 3 = all)
 };
 
 __device__ __forceinline__ void rope8(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
@@ -188,17 +189,21 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
   float q[EW_MAXC][8], k[EW_MAXC][8];
   u32x4 vraw[EW_MAXC];
   float sq = 0.f, sk = 0.f;
+  const bool do_q = a.parts & 1, do_kv = a.parts & 2;   // kernel-uniform
 #pragma unroll
   for (int i = 0; i < EW_MAXC; ++i) {
     int c = threadIdx.x + i * EW_THREADS;
     if (c < nchunks) {
-      unpack_bf16x8(*(const u32x4*)(qr + c * 8), q[i]);
-      unpack_bf16x8(*(const u32x4*)(kr + c * 8), k[i]);
-      vraw[i] = *(const u32x4*)(vr + c * 8);
+      if (do_q) {
+        unpack_bf16x8(*(const u32x4*)(qr + c * 8), q[i]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        sq += q[i][j] * q[i][j];
-        sk += k[i][j] * k[i][j];
+        for (int j = 0; j < 8; ++j) sq += q[i][j] * q[i][j];
+      }
+      if (do_kv) {
+        unpack_bf16x8(*(const u32x4*)(kr + c * 8), k[i]);
+        vraw[i] = *(const u32x4*)(vr + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sk += k[i][j] * k[i][j];
       }
     }
   }
@@ -229,18 +234,21 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
       float wq8[8], wk8[8];
       unpack_bf16x8(*(const u32x4*)(a.wq + c * 8), wq8);
       unpack_bf16x8(*(const u32x4*)(a.wk + c * 8), wk8);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        q[i][j] = round_bf16(round_bf16(q[i][j] * rq) * wq8[j]);
-        k[i][j] = round_bf16(round_bf16(k[i][j] * rk) * wk8[j]);
-      }
-      rope8(q[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
-      rope8(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
       const int g = gc ? (c * 8) / gc : 0;
       const int col = c * 8 - g * gc;
-      *(u32x4*)(qo + g * a.q_group_stride + col) = pack_bf16x8(q[i]);
-      *(u32x4*)(ko + g * a.kv_group_stride + col) = pack_bf16x8(k[i]);
-      *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
+      if (do_q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[i][j] = round_bf16(round_bf16(q[i][j] * rq) * wq8[j]);
+        rope8(q[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
+        *(u32x4*)(qo + g * a.q_group_stride + col) = pack_bf16x8(q[i]);
+      }
+      if (do_kv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[i][j] = round_bf16(round_bf16(k[i][j] * rk) * wk8[j]);
+        rope8(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
+        *(u32x4*)(ko + g * a.kv_group_stride + col) = pack_bf16x8(k[i]);
+        *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
+      }
     }
   }
 }
@@ -320,8 +328,9 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
                         int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
                         const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
                         int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
-                        rtv_stream_t stream) {
+                        int parts, rtv_stream_t stream) {
   if (M <= 0) return 0;
+  if (parts < 1 || parts > 3) return set_error(-1, "qk_norm_rope_cache: parts must be 1 (q), 2 (k, v) or 3");
   if (ring_size < 0 || ring_lo < 0 || ring_shift < 0 || (ring_size > 0 && ring_shift >= ring_size))
     return set_error(-1, "qk_norm_rope_cache: bad ring (need ring_lo >= 0, 0 <= ring_shift < ring_size)");
   if (ring_size > 0 && cache_row0 + row_offset + M > ring_lo + ring_size)
@@ -359,7 +368,8 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   a.ring_lo = ring_lo;
   a.ring_size = ring_size;
   a.ring_shift = ring_shift;
-  ProfScope prof(PROF_ROPE, (hipStream_t)stream, 6.0 * M * d * 2);
+  a.parts = parts;
+  ProfScope prof(PROF_ROPE, (hipStream_t)stream, (parts == 3 ? 6.0 : parts == 1 ? 2.0 : 4.0) * M * d * 2);
   hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
   return check_launch("qk_norm_rope_cache");
 }
@@ -471,7 +481,7 @@ int rtv_qk_norm_rope_cache(const void* qkv, void* q_out, void* k_cache, void* v_
                            const void* wq, const void* wk, const void* rope_cs, int F, int gh, int gw,
                            int start_frame, int row_offset, rtv_stream_t stream) {
   return rtv::qk_norm_rope_launch(qkv, q_out, k_cache, v_cache, cache_row_stride, cache_row0, M, d, num_heads, eps, wq, wk,
-                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, 0, 0, 0, stream);
+                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, 0, 0, 0, 3, stream);
 }
 
 int rtv_qk_norm_rope_cache_ring(const void* qkv, void* q_out, void* k_cache, void* v_cache,
@@ -480,7 +490,7 @@ int rtv_qk_norm_rope_cache_ring(const void* qkv, void* q_out, void* k_cache, voi
                                 int start_frame, int row_offset, int ring_lo, int ring_size, int ring_shift,
                                 rtv_stream_t stream) {
   return rtv::qk_norm_rope_launch(qkv, q_out, k_cache, v_cache, cache_row_stride, cache_row0, M, d, num_heads, eps, wq, wk,
-                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, ring_lo, ring_size, ring_shift, stream);
+                                  rope_cs, F, gh, gw, start_frame, row_offset, 0, 0, 0, ring_lo, ring_size, ring_shift, 3, stream);
 }
 
 int rtv_modulation_table(const void* modulation, const void* e0, void* emod, int L, int F, int J, int J0,

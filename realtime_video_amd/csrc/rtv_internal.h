@@ -33,7 +33,7 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
                         int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
                         const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
                         int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
-                        rtv_stream_t stream);
+                        int parts /* 1 = q, 2 = k and v, 3 = all */, rtv_stream_t stream);
 int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rtv_stream_t stream);
 
 }  // namespace rtv

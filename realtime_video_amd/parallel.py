@@ -46,8 +46,25 @@ class _ExchangeChoice:
         return True
 
 
+class Pending:
+    """A collective in flight (issued with async_op=True on the process group's communication stream, RCCL running beside the
+    compute stream) plus the work that has to follow it; `wait()` makes the CURRENT stream wait for it - the host does not
+    block - and runs the follow-up.  `Pending()` is an already completed exchange."""
+
+    def __init__(self, work=None, after=None):
+        self.work, self.after = work, after
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.after is not None:
+            self.after()
+            self.after = None
+
+
 class ContextParallel(_ExchangeChoice):
-    def __init__(self, group=None, exchange="auto"):
+    def __init__(self, group=None, exchange="auto", overlap=True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -55,6 +72,10 @@ class ContextParallel(_ExchangeChoice):
         self.world = dist.get_world_size(group)
         self._gloo = dist.get_backend(group) == "gloo"
         self.exchange = exchange
+        # overlap=True: the per-layer exchanges are issued asynchronously and waited for right before their consumer, so the
+        # q all-to-all runs under the k|v projection (head exchange) and the K/V all-gather under the q projection (row
+        # exchange); False = every collective completes before the next kernel is issued (A/B, debugging)
+        self.overlap = overlap
 
     def shard(self, M):
         return shard_rows(M, self.world, self.rank)
@@ -62,10 +83,12 @@ class ContextParallel(_ExchangeChoice):
     def local_ranks(self):
         return [self.rank]
 
-    def all_gather_rows_(self, buf):
-        """In-place all-gather along dim 0 of a contiguous buffer whose local shard is already filled."""
+    def all_gather_rows_(self, buf, async_op=False):
+        """In-place all-gather along dim 0 of a contiguous buffer whose local shard is already filled.  async_op: returns a
+        Pending (the collective runs on the communication stream; wait() orders the current stream behind it)."""
+        done = Pending() if async_op else buf
         if self.world == 1:
-            return buf
+            return done
         if not buf.is_contiguous() or buf.shape[0] % self.world:
             raise ValueError("all_gather_rows_ needs a contiguous buffer with rows divisible by the world size")
         n = buf.shape[0] // self.world
@@ -78,57 +101,78 @@ class ContextParallel(_ExchangeChoice):
                 if r != self.rank:
                     buf[r * n:(r + 1) * n].copy_(host[r])
         elif self._gloo:
-            dist.all_gather([buf[r * n:(r + 1) * n] for r in range(self.world)], mine.clone(), group=self.group)
+            work = dist.all_gather([buf[r * n:(r + 1) * n] for r in range(self.world)], mine.clone(), group=self.group,
+                                   async_op=async_op and self.overlap)
+            if async_op:
+                return Pending(work if self.overlap else None)
         else:
-            dist.all_gather_into_tensor(buf, mine, group=self.group)
-        return buf
+            work = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=async_op and self.overlap)
+            if async_op:
+                return Pending(work if self.overlap else None)
+        return done
 
-    def gather_kv(self, k, v, row0, M):
+    def gather_kv(self, k, v, row0, M, async_op=False):
         """All-gather cache rows [row0, row0+M) of one layer's K and V ([kv_size, H, hd] views).  If K and V rows
         are interleaved in one arena ([kv_size, 2, H, hd]) this is ONE collective, otherwise two."""
         if self.world == 1:
-            return
+            return Pending() if async_op else None
         H, hd = k.shape[1], k.shape[2]
         row = H * hd
         inter = (k.stride(0) == 2 * row and v.stride(0) == 2 * row and k.stride(1) == hd and
                  v.data_ptr() == k.data_ptr() + row * k.element_size())
         if inter:
             both = torch.as_strided(k, (M, 2 * row), (2 * row, 1), k.storage_offset() + row0 * 2 * row)
-            self.all_gather_rows_(both)
-        else:
-            if k.stride(0) != row or v.stride(0) != row:
-                raise ValueError("gather_kv needs dense or K/V-interleaved cache rows")
-            self.all_gather_rows_(k[row0:row0 + M])
-            self.all_gather_rows_(v[row0:row0 + M])
-
+            pend = self.all_gather_rows_(both, async_op)
+            return pend if async_op else None
+        if k.stride(0) != row or v.stride(0) != row:
+            raise ValueError("gather_kv needs dense or K/V-interleaved cache rows")
+        p1 = self.all_gather_rows_(k[row0:row0 + M], async_op)
+        p2 = self.all_gather_rows_(v[row0:row0 + M], async_op)
+        return Pending(after=lambda: (p1.wait(), p2.wait())) if async_op else None
 
     # ---- head exchange
-    def all_to_all_(self, out, inp):
+    def all_to_all_(self, out, inp, async_op=False):
         """out[g-th block] <- rank g's inp[rank-th block]; both contiguous with dim 0 divisible by the world size."""
         if not out.is_contiguous() or not inp.is_contiguous() or out.numel() != inp.numel() or out.numel() % self.world:
             raise ValueError("all_to_all_ needs contiguous, equally sized buffers divisible by the world size")
+        work = None
         if self._gloo and inp.is_cuda:      # test-only route, as in all_gather_rows_
             host_out = torch.empty(inp.numel(), dtype=inp.dtype)
             dist.all_to_all_single(host_out, inp.reshape(-1).cpu(), group=self.group)
             out.view(-1).copy_(host_out)
         else:
-            dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group)
-        return out
+            work = dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group, async_op=async_op and self.overlap)
+        return Pending(work if (async_op and self.overlap) else None) if async_op else out
 
-    def exchange_qkv(self, parts, k, v, row0, M):
-        """parts: [(rank, bufs)] of the local rank.  q_send -> q_all, kv_send -> rows [row0, row0+M) of this rank's heads of
-        one layer's K/V cache (k, v: [kv_size, hn or H, hd] views)."""
+    def exchange_q(self, parts, async_op=False):
+        """q_send -> q_all: every rank receives ALL query rows of its own heads."""
         (rank, b), = parts
-        self.all_to_all_(b["q_all"], b["q_send"])
+        return self.all_to_all_(b["q_all"], b["q_send"], async_op)
+
+    def exchange_kv(self, parts, k, v, row0, M, async_op=False):
+        """kv_send -> rows [row0, row0+M) of this rank's heads of one layer's K/V cache (k, v: [kv_size, hn or H, hd] views)."""
+        (rank, b), = parts
         hn, hd = b["hn"], k.shape[2]
         h0 = 0 if k.shape[1] == hn else rank * hn
         rows = _interleaved_rows(k, v, row0, M, h0, hn)
         if rows is not None:
-            self.all_to_all_(rows, b["kv_send"])            # straight into the cache arena
-        else:
-            tmp = self.all_to_all_(torch.empty_like(b["kv_send"]), b["kv_send"]).view(M, 2, hn, hd)
-            k[row0:row0 + M, h0:h0 + hn] = tmp[:, 0]
-            v[row0:row0 + M, h0:h0 + hn] = tmp[:, 1]
+            return self.all_to_all_(rows, b["kv_send"], async_op)            # straight into the cache arena
+        tmp = torch.empty_like(b["kv_send"])
+        pend = self.all_to_all_(tmp, b["kv_send"], async_op)
+
+        def scatter():
+            t = tmp.view(M, 2, hn, hd)
+            k[row0:row0 + M, h0:h0 + hn] = t[:, 0]
+            v[row0:row0 + M, h0:h0 + hn] = t[:, 1]
+        if async_op:
+            return Pending(after=lambda: (pend.wait(), scatter()))
+        scatter()
+        return None
+
+    def exchange_qkv(self, parts, k, v, row0, M):
+        """Both exchanges, completed (the non-overlapped form)."""
+        self.exchange_q(parts)
+        self.exchange_kv(parts, k, v, row0, M)
 
     def exchange_o(self, parts):
         (rank, b), = parts
@@ -161,11 +205,11 @@ class SimulatedContextParallel(_ExchangeChoice):
     def local_ranks(self):
         return list(range(self.world))
 
-    def all_gather_rows_(self, buf):
-        return buf
+    def all_gather_rows_(self, buf, async_op=False):
+        return Pending() if async_op else buf
 
-    def gather_kv(self, k, v, row0, M):
-        return None
+    def gather_kv(self, k, v, row0, M, async_op=False):
+        return Pending() if async_op else None
 
     def exchange_qkv(self, parts, k, v, row0, M):
         """All ranks live in this process and share one full-head cache: the all-to-alls become block copies."""
@@ -178,6 +222,24 @@ class SimulatedContextParallel(_ExchangeChoice):
                 bg["q_all"].view(M, hn * hd)[s * rl:(s + 1) * rl] = qs[g]
                 k[row0 + s * rl:row0 + (s + 1) * rl, g * hn:(g + 1) * hn] = kvs[g][:, 0]
                 v[row0 + s * rl:row0 + (s + 1) * rl, g * hn:(g + 1) * hn] = kvs[g][:, 1]
+
+    def exchange_q(self, parts, async_op=False):
+        rl = parts[0][1]["q_all"].shape[0] // self.world
+        for s, bs in parts:
+            qs = bs["q_send"].view(self.world, rl, -1)
+            for g, bg in parts:
+                bg["q_all"][s * rl:(s + 1) * rl] = qs[g]
+        return Pending() if async_op else None
+
+    def exchange_kv(self, parts, k, v, row0, M, async_op=False):
+        rl = M // self.world
+        for s, bs in parts:
+            hn, hd = bs["hn"], k.shape[2]
+            kvs = bs["kv_send"].view(self.world, rl, 2, hn, hd)
+            for g, bg in parts:
+                k[row0 + s * rl:row0 + (s + 1) * rl, g * hn:(g + 1) * hn] = kvs[g][:, 0]
+                v[row0 + s * rl:row0 + (s + 1) * rl, g * hn:(g + 1) * hn] = kvs[g][:, 1]
+        return Pending() if async_op else None
 
     def exchange_o(self, parts):
         for s, bs in parts:

@@ -81,6 +81,7 @@ def main():
             k["hbm_read_bytes_per_launch"] = rd
             k["hbm_write_bytes_per_launch"] = wr
             k["hbm_bytes_per_launch"] = rd + wr
+            k["launches_sampled"] = min(k["fetch_kib_launches"], k["write_kib_launches"])
             lines.append(f"traffic {name:10s} launches {k['fetch_kib_launches']:6d}  read {rd/1e6:10.2f} MB  write {wr/1e6:10.2f} MB per launch")
     txt = "\n".join(lines)
     print(txt)

@@ -75,15 +75,21 @@ def _cp_block(w, x_local, e, ctx, k_cache, v_cache, row0, cp, M):
         bufs = {"hn": hn, "q_send": rope_local(q).reshape(rc, W, gc).transpose(0, 1).contiguous(),
                 "kv_send": torch.stack([rope_local(k).reshape(rc, W, gc), v.reshape(rc, W, gc)], 2).transpose(0, 1).contiguous(),
                 "q_all": torch.empty(M, gc), "o_all": None, "o_recv": torch.empty(W, rc, gc)}
-        cp.exchange_qkv([(cp.rank, bufs)], k_cache[0], v_cache[0], row0, M)
+        # the overlapped form the GPU path uses: both exchanges in flight, waited for right before attention
+        pend_q = cp.exchange_q([(cp.rank, bufs)], async_op=True)
+        pend_kv = cp.exchange_kv([(cp.rank, bufs)], k_cache[0], v_cache[0], row0, M, async_op=True)
+        pend_q.wait()
+        pend_kv.wait()
         bufs["o_all"] = _attn(bufs["q_all"].view(1, M, hn, 128), k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0].reshape(M, gc)
         cp.exchange_o([(cp.rank, bufs)])
         out = bufs["o_recv"].transpose(0, 1).reshape(rc, H, 128)
     else:
         k_cache[0, row0 + r0:row0 + r0 + rc] = rope_local(k)
         v_cache[0, row0 + r0:row0 + r0 + rc] = v
-        cp.gather_kv(k_cache[0], v_cache[0], row0, M)                   # the one exchange of the layer
-        out = _attn(rope_local(q).unsqueeze(0), k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0]
+        pend = cp.gather_kv(k_cache[0], v_cache[0], row0, M, async_op=True)   # the one exchange of the layer, in flight ...
+        rq = rope_local(q).unsqueeze(0)                                       # ... under the q projection's RoPE
+        pend.wait()
+        out = _attn(rq, k_cache[:, :row0 + M], v_cache[:, :row0 + M])[0]
     x = x_local + lin(out.flatten(1), sa + ".o") * em[:, 2]
     ca = pre + ".cross_attn"
     hq = wo.rms_norm(lin(wo.layer_norm(x, 1e-6, w[pre + ".norm3.weight"], w[pre + ".norm3.bias"]), ca + ".q"),
