@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtv_hip.so")
+# RTV_LIB_PATH: A/B measurements against another build of the same C ABI (scripts/ab_build.sh); never set in production
+LIB_PATH = os.environ.get("RTV_LIB_PATH") or os.path.join(_HERE, "librtv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
