@@ -243,7 +243,22 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   const bool wide = !((p.ldc | (p.residual ? p.ldr : 0)) & 7) && !(((uintptr_t)p.C | (uintptr_t)p.residual) & 15);
   if (wide) {
     if (is_split) __syncthreads();   // the reducer's flag word lives in smem[0..4)
+#ifdef RTV_GEMM_TIMELINE
+    unsigned long long tl_mid = 0;
+    store_tile_lds<F16, 4>(p, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * 128), acc, &tl_mid);
+    if (g_timeline && tid == 0) g_timeline[(size_t)blockIdx.x * 4 + 1] = tl_mid | (1ull << 63);   // replaces the K-loop stamp
+    tl_t1 = tl_t1 ? tl_t1 : 0;
+    if (g_timeline && tid == 0) {
+      unsigned long long* t = g_timeline + (size_t)blockIdx.x * 4;
+      t[0] = tl_t0;
+      t[2] = __builtin_amdgcn_s_memrealtime();
+      t[3] = ((unsigned long long)(is_split ? seg + 1 : 0) << 32) | (unsigned)tile_id;
+      g_timeline[(size_t)(gridDim.x + blockIdx.x) * 4] = tl_t1;    // K-loop end in the second half of the buffer
+    }
+    return;
+#else
     store_tile_lds<F16, 4>(p, m0 + wr * 128, n0 + wc * 64, lane, smem + wave * (128 * 128), acc);
+#endif
   } else {
     store_tile<F16, Cfg>(p, m0 + wr * 128, n0 + wc * 64, lane, acc);
   }

@@ -196,53 +196,63 @@ __device__ __forceinline__ void store_tile(const GemmParams& p, int m_base, int 
 // Same rounding points as epilogue_quad (y = bf16(acc + bias); y = bf16(act(y)); t = bf16(y * gate); out = bf16(res + t)):
 // a value is only rounded when another operation follows; the staged value is t, the residual is added in f32 afterwards.
 // `img`: TM*32*128 bytes of LDS owned by this wave; the caller guarantees nobody still reads that LDS (barrier).
-template <bool F16, int TM>
-__device__ __forceinline__ void store_tile_lds(const GemmParams& p, int m_base, int n_base, int lane, char* img,
-                                               f32x16 (&acc)[TM][2]) {
+template <bool F16, int TM, int ACT, bool GATE>
+__device__ __forceinline__ void store_tile_lds_impl(const GemmParams& p, int m_base, int n_base, int lane, char* img,
+                                                    f32x16 (&acc)[TM][2], unsigned long long* mid_stamp) {
   typedef Mfma32<F16> T;
   const int l31 = lane & 31, g = lane >> 5;
+  // the bias (and gate) quads of this lane's 8 column slots, fetched as ONE batch of loads up front: left inside the loop
+  // they are 32 dependent round trips to L2 per lane (measured 7 us of an 10 us epilogue, profiles/r02_gemm_timeline_*.log)
+  int ncol[8];
+  u32x2 bq[8];
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    ncol[s8] = min(n_base + (s8 >> 2) * 32 + (s8 & 3) * 8 + g * 4, p.N - 4);
+    bq[s8] = p.bias ? *(const u32x2*)(p.bias + ncol[s8]) : u32x2{0u, 0u};
+  }
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     const int row = mi * 32 + l31;
-    const uint16_t* gp = nullptr;
-    if (p.gate) gp = p.gate + (size_t)((p.row_offset + min(m_base + row, p.M - 1)) / p.rows_per_frame) * p.gate_stride;
+    u32x2 gq[8];
+    if (GATE) {
+      const uint16_t* gp = p.gate + (size_t)((p.row_offset + min(m_base + row, p.M - 1)) / p.rows_per_frame) * p.gate_stride;
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) gq[s8] = *(const u32x2*)(gp + ncol[s8]);
+    }
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const int nc = min(n_base + ni * 32 + rq * 8 + g * 4, p.N - 4);
+        const int s8 = ni * 4 + rq;
         float v[4] = {acc[mi][ni][rq * 4 + 0], acc[mi][ni][rq * 4 + 1], acc[mi][ni][rq * 4 + 2], acc[mi][ni][rq * 4 + 3]};
-        if (p.bias) {
-          const u32x2 b = *(const u32x2*)(p.bias + nc);
-          v[0] += T::lo_f32(b[0]);
-          v[1] += T::hi_f32(b[0]);
-          v[2] += T::lo_f32(b[1]);
-          v[3] += T::hi_f32(b[1]);
-        }
-        if (p.act == 1) {
+        v[0] += T::lo_f32(bq[s8][0]);   // (zero quads without a bias: + 0 is exact)
+        v[1] += T::hi_f32(bq[s8][0]);
+        v[2] += T::lo_f32(bq[s8][1]);
+        v[3] += T::hi_f32(bq[s8][1]);
+        if (ACT == 1) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = gelu_tanh(T::round(v[i]));
-        } else if (p.act == 2) {
+        } else if (ACT == 2) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i] = silu(T::round(v[i]));
         }
-        if (p.gate) {
-          const u32x2 gg = *(const u32x2*)(gp + nc);
-          v[0] = T::round(v[0]) * T::lo_f32(gg[0]);
-          v[1] = T::round(v[1]) * T::hi_f32(gg[0]);
-          v[2] = T::round(v[2]) * T::lo_f32(gg[1]);
-          v[3] = T::round(v[3]) * T::hi_f32(gg[1]);
+        if (GATE) {
+          v[0] = T::round(v[0]) * T::lo_f32(gq[s8][0]);
+          v[1] = T::round(v[1]) * T::hi_f32(gq[s8][0]);
+          v[2] = T::round(v[2]) * T::lo_f32(gq[s8][1]);
+          v[3] = T::round(v[3]) * T::hi_f32(gq[s8][1]);
         }
         u32x2 o;
         o[0] = T::pack2(v[0], v[1]);
         o[1] = T::pack2(v[2], v[3]);
-        const int chunk = (ni * 4 + rq) ^ (row & 7);
+        const int chunk = s8 ^ (row & 7);
         const int half = g ^ ((row >> 3) & 1);
         *(u32x2*)(img + row * 128 + chunk * 16 + half * 8) = o;
       }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
+  if (mid_stamp) *mid_stamp = __builtin_amdgcn_s_memrealtime();   // lab builds: end of the register -> LDS pass
   const int rsub = lane >> 3, c = lane & 7;
   const int n = n_base + c * 8;
   const bool n_ok = n < p.N;
@@ -267,6 +277,22 @@ __device__ __forceinline__ void store_tile_lds(const GemmParams& p, int m_base, 
         t[i] = T::pack2(T::lo_f32(t[i]) + T::lo_f32(res[ps][i]), T::hi_f32(t[i]) + T::hi_f32(res[ps][i]));
     }
     if (m < p.M && n_ok) *(u32x4*)(p.C + (size_t)m * p.ldc + n) = t;
+  }
+}
+
+// One branch on the epilogue kind, then straight-line code: with the activation / gate tests inside the 32 quads of a
+// lane the epilogue was 100+ tiny basic blocks that the scheduler could not overlap (7 us of the 10 us epilogue).
+template <bool F16, int TM>
+__device__ __forceinline__ void store_tile_lds(const GemmParams& p, int m_base, int n_base, int lane, char* img,
+                                               f32x16 (&acc)[TM][2], unsigned long long* mid_stamp = nullptr) {
+  if (p.gate) {
+    if (p.act == 0) store_tile_lds_impl<F16, TM, 0, true>(p, m_base, n_base, lane, img, acc, mid_stamp);
+    else if (p.act == 1) store_tile_lds_impl<F16, TM, 1, true>(p, m_base, n_base, lane, img, acc, mid_stamp);
+    else store_tile_lds_impl<F16, TM, 2, true>(p, m_base, n_base, lane, img, acc, mid_stamp);
+  } else {
+    if (p.act == 0) store_tile_lds_impl<F16, TM, 0, false>(p, m_base, n_base, lane, img, acc, mid_stamp);
+    else if (p.act == 1) store_tile_lds_impl<F16, TM, 1, false>(p, m_base, n_base, lane, img, acc, mid_stamp);
+    else store_tile_lds_impl<F16, TM, 2, false>(p, m_base, n_base, lane, img, acc, mid_stamp);
   }
 }
 

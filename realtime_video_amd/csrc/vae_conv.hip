@@ -46,9 +46,31 @@ struct ConvParams {
   int tiles_m, tiles_n;
 };
 
+// Wave-private LDS image of a TM*32 x TN*32 output block (rows of TN*64 bytes) for the coalesced epilogue: 16-byte
+// chunk c of row r is stored at a permuted position so that both the ds_write_b64 of the MFMA layout (32 rows x one
+// 8-byte column slot per instruction) and the row-contiguous ds_read_b128 are bank-conflict free.
+template <int TN>
+__device__ __forceinline__ int conv_img_off(int row, int chunk, int half) {
+  if constexpr (TN == 2)
+    return row * 128 + ((chunk ^ (row & 7)) << 4) + ((half ^ ((row >> 3) & 1)) << 3);
+  else   // 4 or 12 chunks per row: row bases repeat every 4 rows (64 / 192-byte rows), so rows r, r+4, r+8, r+12 get
+    return row * (TN * 64) + ((chunk ^ ((row >> 2) & 3)) << 4) + (half << 3);   // different chunks of a group of 4
+}
+
+// Implicit-GEMM convolution, one BM-pixel x BN-filter tile per workgroup.
+//  * K runs over (tap, channel slab of BK); the im2col rows of a slab are gathered straight into LDS by global_load_lds.
+//    The per-lane source pointers are rebuilt only when the TAP changes (row / column offsets of the 3 x 3 neighbours and
+//    their in-image bits are precomputed per lane), a slab step just adds the uniform channel offset: ~25 VALU per
+//    K-step and wave instead of ~90 in the round-1 kernel, where address arithmetic competed with the MFMAs for issue.
+//  * three LDS stages, the DMA two K-steps ahead, ONE raw s_barrier per step and a counted s_waitcnt vmcnt (round 1: two
+//    stages, the DMA of step k+1 issued and waited for inside step k behind __syncthreads' full drain);
+//  * epilogue through LDS: every lane stores 16 contiguous bytes of an output pixel row (round 1: 8-byte stores at a
+//    pixel stride - the same store tail that cost the GEMM a third of its time, profiles/r02_gemm_lab_v2_vs_v1.log).
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   typedef TileCfg<BM, BN, BK, WM, WN> Cfg;
+  constexpr int STAGES = 3;
+  constexpr int PIECES = Cfg::A_INST + Cfg::B_INST;   // DMA instructions per wave and K-step
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -63,17 +85,30 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   const int cpos = lane % Cfg::CH;
   const int rsub = lane / Cfg::CH;
   const int HW = p.H * p.W;
-  // per-lane pixel coordinates of the A rows this lane stages
-  int pt[Cfg::A_INST], py[Cfg::A_INST], px[Cfg::A_INST], a_chunk[Cfg::A_INST];
+  // ---- per-lane gather state of the A rows this lane stages.  The source of tap (dt, dy, dx) is the pixel's own input
+  //      position plus a UNIFORM offset: ((dt * inH + dy) * inW + dx) * Cin without upsampling; with the nearest-2x
+  //      upsampling folded into the gather the source row of output row y + dy is (y + dy) >> 1 = (y >> 1) + floor((dy +
+  //      (y & 1)) / 2), i.e. one of two uniform offsets chosen by the parity of the lane's row (same for columns).  Per lane:
+  //      the base offset, the parities and the in-image bits of its 3 x 3 neighbourhood.
+  int base_off[Cfg::A_INST], flags[Cfg::A_INST];   // flags: bits 0-2 row k in image, 3-5 column k in image, 6 row odd, 7 col odd
 #pragma unroll
   for (int i = 0; i < Cfg::A_INST; ++i) {
-    int row = (wave * Cfg::A_INST + i) * Cfg::RPI + rsub;
-    int m = min(m0 + row, p.M - 1);
-    pt[i] = m / HW;
-    int rem = m - pt[i] * HW;
-    py[i] = rem / p.W;
-    px[i] = rem - py[i] * p.W;
-    a_chunk[i] = Cfg::swz(row, cpos) * 8;
+    const int row = (wave * Cfg::A_INST + i) * Cfg::RPI + rsub;
+    const int m = min(m0 + row, p.M - 1);
+    const int pt = m / HW;
+    const int rem = m - pt * HW;
+    const int py = rem / p.W, px = rem - py * p.W;
+    const int yb = p.y_out0 + py * p.sy, xb = px * p.sy;
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int yy = yb + k - p.pad_h, xx = xb + k - p.pad_w;
+      if (yy >= 0 && yy < p.limH) f |= 1 << k;
+      if (xx >= 0 && xx < p.limW) f |= 8 << k;
+    }
+    if (p.ups) f |= ((yb & 1) << 6) | ((xb & 1) << 7);
+    flags[i] = f;
+    base_off[i] = ((pt * p.st * p.inH + ((yb >> p.ups) - p.y_in0)) * p.inW + (xb >> p.ups)) * p.Cin + Cfg::swz(row, cpos) * 8;
   }
   uint32_t b_off[Cfg::B_INST];
   const int Ktot = p.kt * p.kh * p.kw * p.Cin;
@@ -85,29 +120,50 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   }
   const int cpk = p.Cin / BK;  // K-steps per tap
   const int nk = p.kt * p.kh * p.kw * cpk;
+  const int slice = p.inH * p.inW * p.Cin;   // elements per input time slice
 
-  auto stage = [&](int ks, int buf) {
-    char* sA = smem + buf * Cfg::STAGE_BYTES;
-    char* sB = sA + Cfg::A_BYTES;
-    const int tap = ks / cpk;
-    const int c0 = (ks - tap * cpk) * BK;
-    const int dt = tap / (p.kh * p.kw);
-    const int r2 = tap - dt * (p.kh * p.kw);
-    const int dy = r2 / p.kw - p.pad_h;
-    const int dx = r2 - (r2 / p.kw) * p.kw - p.pad_w;
+  // ---- DMA issue cursor (uniform): tap (dt, dy, dx) and the channel slab inside it
+  int is_dt = 0, is_dy = 0, is_dx = 0, is_c = 0, is_ks = 0;
+  const uint16_t* a_src[Cfg::A_INST];   // source of the current tap's row for this lane (zero page when outside the image)
+  int a_live[Cfg::A_INST];              // 1: add the slab offset, 0: the zero page is read at offset 0
+  auto tap_setup = [&]() __attribute__((always_inline)) {
+    // uniform offsets of this tap for even / odd output rows and columns (equal without upsampling)
+    const int ry = is_dy - p.pad_h, rx = is_dx - p.pad_w;
+    const int row_e = p.ups ? (ry >> 1) : ry, row_o = p.ups ? ((ry + 1) >> 1) : ry;     // arithmetic shift = floor
+    const int col_e = p.ups ? (rx >> 1) : rx, col_o = p.ups ? ((rx + 1) >> 1) : rx;
+    const int t_off = is_dt * slice;
+    const int d_re = t_off + row_e * p.inW * p.Cin, d_ro = t_off + row_o * p.inW * p.Cin;
+    const int d_ce = col_e * p.Cin, d_co = col_o * p.Cin;
 #pragma unroll
     for (int i = 0; i < Cfg::A_INST; ++i) {
-      const int yy = p.y_out0 + py[i] * p.sy + dy, xx = px[i] * p.sy + dx;
-      const bool ok = (yy >= 0) & (yy < p.limH) & (xx >= 0) & (xx < p.limW);
-      const int ti = pt[i] * p.st + dt;
-      const int sy_ = min(max((yy >> p.ups) - p.y_in0, 0), p.in_rows - 1);
-      const size_t off = ((size_t)(ti * p.inH + sy_) * p.inW + (xx >> p.ups)) * p.Cin + c0 + a_chunk[i];
-      const uint16_t* src = ok ? p.in + off : p.zeros;
-      dma16(src, sA + (wave * Cfg::A_INST + i) * 1024);
+      const int f = flags[i];
+      const bool ok = ((f >> is_dy) & (f >> (3 + is_dx)) & 1) != 0;
+      const int off = base_off[i] + ((f & 64) ? d_ro : d_re) + ((f & 128) ? d_co : d_ce);
+      a_src[i] = ok ? p.in + (ptrdiff_t)off : p.zeros;
+      a_live[i] = ok ? 1 : 0;
     }
-    const uint16_t* Wk = p.w + (size_t)ks * BK;
+  };
+  auto issue = [&]() __attribute__((always_inline)) {   // stage K-step is_ks into slot is_ks % STAGES, advance the cursor
+    char* sA = smem + (is_ks % STAGES) * Cfg::STAGE_BYTES;
+    char* sB = sA + Cfg::A_BYTES;
+    if (is_c == 0) tap_setup();
+#pragma unroll
+    for (int i = 0; i < Cfg::A_INST; ++i) dma16(a_src[i] + a_live[i] * is_c, sA + (wave * Cfg::A_INST + i) * 1024);
+    const uint16_t* Wk = p.w + (size_t)is_ks * BK;
 #pragma unroll
     for (int i = 0; i < Cfg::B_INST; ++i) dma16(Wk + b_off[i], sB + (wave * Cfg::B_INST + i) * 1024);
+    ++is_ks;
+    is_c += BK;
+    if (is_c == p.Cin) {
+      is_c = 0;
+      if (++is_dx == p.kw) {
+        is_dx = 0;
+        if (++is_dy == p.kh) {
+          is_dy = 0;
+          ++is_dt;
+        }
+      }
+    }
   };
 
   f32x16 acc[Cfg::TM][Cfg::TN];
@@ -121,17 +177,96 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   const int wm = wave / WN, wn = wave % WN;
   const int a_row0 = wm * (BM / WM), b_row0 = wn * (BN / WN);
 
-  stage(0, 0);
+#define CV_FENCE() __builtin_amdgcn_sched_barrier(0)
+  issue();
+  if (nk > 1) issue();
   for (int ks = 0; ks < nk; ++ks) {
-    const int buf = ks & 1;
-    __syncthreads();
-    if (ks + 1 < nk) stage(ks + 1, buf ^ 1);
-    const char* sA = smem + buf * Cfg::STAGE_BYTES;
+    // step ks has landed for this wave (the pieces of step ks + 1 may stay in flight) ...
+    if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CV_FENCE();
+    __builtin_amdgcn_s_barrier();   // ... and for every wave; everybody is done reading the slot of step ks - 1
+    CV_FENCE();
+    if (ks + 2 < nk) issue();       // -> slot (ks + 2) % 3 = the slot of step ks - 1
+    CV_FENCE();
+    const char* sA = smem + (ks % STAGES) * Cfg::STAGE_BYTES;
     mma_stage<true, Cfg, BK>(sA, sA + Cfg::A_BYTES, a_row0, b_row0, lane, acc);
+    CV_FENCE();
   }
+  __builtin_amdgcn_s_barrier();     // all fragment reads done: the stage buffers become the epilogue image
+  CV_FENCE();
+#undef CV_FENCE
 
-  // ---- epilogue: bias (+ residual), optional channel-half -> frame scatter
+  // ---- epilogue: bias (+ residual), optional channel-half -> frame scatter, through a wave-private LDS image so that every
+  //      lane moves 16 contiguous bytes of a pixel's channels
+  constexpr int TM = Cfg::TM, TN = Cfg::TN, CPR = TN * 4;   // 16-byte chunks per image row
+  char* img = smem + wave * (TM * 32 * TN * 64);
   const int l31 = lane & 31, g = lane >> 5;
+  const bool wide = !((p.out_ld | (p.residual ? p.res_ld : 0) | p.n_split) & 7) &&
+                    !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15);
+  if (wide) {
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+      const int row = mi * 32 + l31;
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int n = min(n0 + b_row0 + ni * 32 + rq * 8 + g * 4, p.Cout - 4);
+          float v[4] = {acc[mi][ni][rq * 4 + 0], acc[mi][ni][rq * 4 + 1], acc[mi][ni][rq * 4 + 2], acc[mi][ni][rq * 4 + 3]};
+          if (p.bias) {
+            const u32x2 bb = *(const u32x2*)(p.bias + n);
+            v[0] += f16_to_f32(bb[0] & 0xffff);
+            v[1] += f16_to_f32(bb[0] >> 16);
+            v[2] += f16_to_f32(bb[1] & 0xffff);
+            v[3] += f16_to_f32(bb[1] >> 16);
+          }
+          u32x2 o;
+          o[0] = pack_f16x2(v[0], v[1]);
+          o[1] = pack_f16x2(v[2], v[3]);
+          *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, g)) = o;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PASSES = TM * 32 * CPR / 64;
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int q = ps * 64 + lane;
+      const int row = q / CPR, c = q - row * CPR;
+      const int m = m0 + a_row0 + row;
+      const int n = n0 + b_row0 + c * 8;
+      u32x4 t;
+      if constexpr (TN == 2) {
+        t = *(const u32x4*)(img + conv_img_off<TN>(row, c, 0) - (((row >> 3) & 1) << 3));   // chunk start; halves swapped on odd octets
+        if ((row >> 3) & 1) t = u32x4{t[2], t[3], t[0], t[1]};
+      } else {
+        t = *(const u32x4*)(img + conv_img_off<TN>(row, c, 0));
+      }
+      if (m >= p.M || n >= p.Cout) continue;
+      if (p.residual) {
+        const u32x4 rr = *(const u32x4*)(p.residual + (size_t)m * p.res_ld + n);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float a0, a1, r0, r1;
+          unpack_f16x2(t[i], a0, a1);
+          unpack_f16x2(rr[i], r0, r1);
+          t[i] = pack_f16x2(a0 + r0, a1 + r1);
+        }
+      }
+      size_t drow = (size_t)m;
+      int ch = n;
+      if (p.n_split > 0) {
+        const int tt = m / HW, pix = m - tt * HW;
+        const int half = n >= p.n_split ? 1 : 0;
+        drow = (size_t)(2 * tt + half) * HW + pix;
+        ch = n - half * p.n_split;
+      }
+      *(u32x4*)(p.out + drow * p.out_ld + ch) = t;
+    }
+    return;
+  }
+  // narrow fallback (channel strides / pointers that do not allow 16-byte accesses): 8-byte stores from the MFMA layout
 #pragma unroll
   for (int mi = 0; mi < Cfg::TM; ++mi) {
     const int m = m0 + a_row0 + mi * 32 + l31;
@@ -182,7 +317,8 @@ static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   typedef TileCfg<BM, BN, BK, WM, WN> Cfg;
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Cout + BN - 1) / BN;
-  const int lds = 2 * Cfg::STAGE_BYTES;
+  const int lds = 3 * Cfg::STAGE_BYTES;
+  static_assert(Cfg::NW * Cfg::TM * 32 * Cfg::TN * 64 <= 3 * Cfg::STAGE_BYTES, "epilogue image must fit the stage buffers");
   auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -27,7 +27,7 @@ def run(M, N, K, cfg):
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(N, device="cuda").to(torch.bfloat16)
     c = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    tl = torch.zeros(4096 * 4, dtype=torch.int64, device="cuda")
+    tl = torch.zeros(8192 * 4, dtype=torch.int64, device="cuda")
     s = vp(torch.cuda.current_stream().cuda_stream)
 
     def go():
@@ -49,8 +49,19 @@ def run(M, N, K, cfg):
     go()
     torch.cuda.synchronize()
     lib.rtv_gemm_debug_timeline(vp(0))
-    t = tl.cpu().numpy().reshape(-1, 4)
-    t = t[t[:, 0] != 0]
+    raw = tl.cpu().numpy().reshape(-1, 4)
+    grid = int((raw[:, 0] != 0).sum() // 2) if (raw[:, 1] < 0).any() else 0
+    if grid:   # LDS-epilogue build: [grid..2 grid) holds the K-loop end, column 1 the end of the register -> LDS pass
+        ng = int(np.nonzero(raw[:, 2])[0].max()) + 1
+        kend_rt = raw[ng:2 * ng, 0].copy()
+        mid = raw[:ng, 1] & 0x7fffffffffffffff
+        t0g = raw[:ng, 0]
+        ok = raw[:ng, 2] != 0
+        print(f"   epilogue split (us): K loop end -> LDS image written: median {np.median((mid - kend_rt)[ok]) / 100.0:.2f}, "
+              f"image -> all stores issued: median {np.median((raw[:ng, 2] - mid)[ok]) / 100.0:.2f}")
+        raw = raw[:ng].copy()
+        raw[:, 1] = kend_rt
+    t = raw[raw[:, 0] != 0]
     if len(t) == 0:
         print(f'== M {M} N {N} K {K} cfg {cfg}: {ms * 1e3:.0f} us - no timeline (problem ran on the 128x128 kernel)')
         return
