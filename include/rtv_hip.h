@@ -91,7 +91,7 @@ int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc,
 /* tile_cfg: 0 = default (gemm8 + split-K when the problem fills the chip with 256x256 tiles, else 128x128);
  * 1 = 128x128 tiles (2 workgroups per CU); 2/3 = 256x128 / 256x256 simple double buffer;
  * 4 = 256x256 ping-pong pipeline (gemm8.hip); 5 = 4 + split-K of the last partial round of tiles (needs a
- * workspace, below); 50..53 = A/B builds of 5 with one schedule detail changed (all compute the same result).
+ * workspace, below); 6 / 7 = the 128x256 ping-pong variant for few-row problems without / with that split-K.
  * The split-K partial sums live in a caller-owned fp32 workspace.  A workspace must not be used by two launches that can
  * overlap in time, so it is attached per (device, stream): rtv_gemm_set_stream_workspace(stream, ...) for launches on that
  * stream of the CURRENT device; rtv_gemm_set_workspace(...) attaches a device-wide default used by the streams that have none

@@ -120,10 +120,15 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
   const bool f16 = dtype == RTV_DTYPE_F16;
   if (dtype != RTV_DTYPE_BF16 && dtype != RTV_DTYPE_F16) return set_error(-1, "gemm: dtype");
   if (tile_cfg == 0) {
-    // default: the 256x256 ping-pong kernel (+ split-K of the tail round) once there is enough work to fill the
-    // chip with 256x256 tiles, the 128x128 kernel (2 workgroups per CU) otherwise.  Thresholds from
-    // profiles/r01_kbench_*.
-    const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    // default: the ping-pong kernels (+ split-K of the tail round) once there is enough work for their big tiles - the
+    // 256x256 one, or its 128x256 variant when 256-row tiles would waste many rows or leave the chip under-filled (token
+    // shards of context parallelism: 585 rows = 3 x 256 wastes 24 %, 5 x 128 8.6 %) - the 128x128 kernel (2 workgroups per
+    // CU) otherwise.  Thresholds from profiles/r01_kbench_*, profiles/r02_gemm_shapes_*.
+    const long tiles_n = (p.N + 255) / 256;
+    const long tiles256 = (long)((p.M + 255) / 256) * tiles_n, tiles128 = (long)((p.M + 127) / 128) * tiles_n;
+    const long pad256 = (long)((p.M + 255) / 256) * 256, pad128 = (long)((p.M + 127) / 128) * 128;
+    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < pad256 * 93 || tiles256 < 256))
+      return launch_gemm8m(p, f16, true, stream);
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
     // along K over the idle CUs, scripts/cp_gemm_shapes.py)
     if (!f16 && ((p.K >= 2048 && tiles256 >= 128) || tiles256 >= 640 || (p.K >= 8192 && tiles256 >= 64)))
@@ -145,6 +150,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     case 5:
     case 50:
       return launch_gemm8(p, f16, true, stream);    // + split-K of the tail round = the default for large problems
+    case 6:
+      return launch_gemm8m(p, f16, false, stream);  // 128x256 ping-pong kernel (few-row problems), no split-K
+    case 7:
+      return launch_gemm8m(p, f16, true, stream);   // + split-K
     default:
       return set_error(-1, "gemm: unknown tile config");
   }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 #ifdef RTV_GEMM_TIMELINE
   tl_t1 = __builtin_amdgcn_s_memrealtime();
   bool reducer = true;
-  if (is_split) reducer = split_k_reduce(acc, sp, unit, seg, tile_id, smem, tid, wave, lane);
+  if (is_split) reducer = split_k_reduce<4>(acc, sp, unit, seg, tile_id, smem, tid, wave, lane);
   if (!reducer) {
     if (g_timeline && tid == 0) {
       unsigned long long* t = g_timeline + (size_t)blockIdx.x * 4;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     return;
   }
 #else
-  if (is_split && !split_k_reduce(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
+  if (is_split && !split_k_reduce<4>(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
 #endif
 
   // ---- epilogue through LDS when the output / residual rows allow 16-byte accesses (always on the DiT path)
@@ -271,6 +271,171 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     t[3] = ((unsigned long long)(is_split ? seg + 1 : 0) << 32) | (unsigned)tile_id | (is_split ? 0x80000000u : 0u);
   }
 #endif
+}
+
+// ---------------------------------------------------------------- 128-row variant (token shards of context parallelism)
+// The same ping-pong on a 128 x 256 tile for problems with few rows (585-row token shards at 8-way context parallelism:
+// three 256-row tiles waste 24 % of their rows and leave most CUs idle).  A wave owns 64 x 64 of the tile, so a K-tile is
+// ONE 16-MFMA segment per wave: two barrier intervals per K-tile,
+//     interval 2t: g0 LDS(t) [A m0,m1 + W n0,n1: 16 reads] | g1 MFMA(t-1)        interval 2t+1: g0 MFMA(t) | g1 LDS(t)
+// and every operand has THREE K-tile buffers (3 x {A 16 KiB, W 2 x 16 KiB} = 144 KiB).  A tile read in interval 2t (g0) /
+// 2t+1 (g1) is dead from 2t+2 on.  Because group 1 runs one interval later but group 0 reads a tile first, group 1 stages
+// one K-tile further ahead: MFMA(t) stages K-tile t + 2 + group (6 pieces per wave) into buffer (t + 2 + group) % 3, then
+// waits with vmcnt(6) - everything but the pieces it has just issued - so each piece is in flight for two to three
+// intervals before the counted wait retires it, one barrier before its first reader.
+namespace g8m {
+constexpr int BM = 128, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
+constexpr int LDS_BYTES = 9 * HALF_BYTES;    // 144 KiB: 3 buffers x {A, W rows 0-127, W rows 128-255}
+}  // namespace g8m
+
+template <bool F16>
+__global__ __launch_bounds__(g8::THREADS, 2) void gemm8m_kernel(GemmParams p, SplitArgs sp) {
+  using namespace g8m;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l31 = lane & 31, g = lane >> 5;
+
+  const int nk_total = p.K / BK;
+  int tile_id, seg, unit, kt_begin, kt_end;
+  const bool is_split = split_unit_of_block(sp, blockIdx.x, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = tile_id / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = tile_id - group * per_group;
+  const int m0 = (first_m + in_group % gm) * BM;
+  const int n0 = (in_group / gm) * BN;
+
+  uint32_t src_off[3][2];  // [A, W0, W1][piece]: byte offsets at k = 0
+  {
+    const int rsub = lane >> 3, cpos = lane & 7;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 64 + wave * 8 + rsub;
+      const int ch = g8::swz(row, cpos) * 8;
+      src_off[0][j] = ((uint32_t)min(m0 + row, p.M - 1) * (uint32_t)p.lda + ch) * 2u;
+      src_off[1][j] = ((uint32_t)min(n0 + row, p.N - 1) * (uint32_t)p.ldw + ch) * 2u;
+      src_off[2][j] = ((uint32_t)min(n0 + 128 + row, p.N - 1) * (uint32_t)p.ldw + ch) * 2u;
+    }
+  }
+  __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, 0x7fffffff, 0x00020000);
+  auto stage_piece = [&](int kt, int b3, int h, int j, auto chk) {  // h: 0 = A, 1 = W rows 0-127, 2 = W rows 128-255; b3 = buffer
+    if (decltype(chk)::value && kt >= kt_end) return;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(h == 0 ? rsrcA : rsrcW,
+                                             (RTV_LDS void*)(smem + (b3 * 3 + h) * HALF_BYTES + (j * 64 + wave * 8) * 128), 16,
+                                             src_off[h][j], (unsigned)kt * (BK * 2), 0, 0);
+  };
+
+  u32x4 af[2][4], bfr[2][4];
+  auto read_frags = [&](int b3) {
+    const char* sa = smem + (b3 * 3) * HALF_BYTES;
+    const char* sw = smem + (b3 * 3 + 1 + (wc >> 1)) * HALF_BYTES;
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+      const int row = (wc & 1) * 64 + nq * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[nq][ks] = *(const u32x4*)(sw + row * 128 + (g8::swz(row, ks * 2 + g) << 4));
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const int row = wr * 64 + mb * 32 + l31;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) af[mb][ks] = *(const u32x4*)(sa + row * 128 + (g8::swz(row, ks * 2 + g) << 4));
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // ---- prologue: K-tiles 0 and 1 by everybody, K-tile 2 by group 1 (what its MFMA(-1) would have staged)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+      stage_piece(kt_begin + t, t, h, 0, std::true_type{});
+      stage_piece(kt_begin + t, t, h, 1, std::true_type{});
+    }
+  if (wr == 1) {
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+      stage_piece(kt_begin + 2, 2, h, 0, std::true_type{});
+      stage_piece(kt_begin + 2, 2, h, 1, std::true_type{});
+    }
+  }
+  // group 0: K-tile 0 landed, K-tile 1 stays in flight (retired at the end of its MFMA(0)).  Group 1 stands where the end of
+  // its MFMA(-1) would be: everything but the youngest tile (2) retired - group 0 reads K-tile 1 in interval 2, before group 1's
+  // first counted wait.
+  if (wr == 1) {
+    if (kt_begin + 2 < kt_end) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    if (kt_begin + 1 < kt_end) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  G8_BARRIER();
+  if (wr == 1) G8_BARRIER();  // stagger: group 1 runs one barrier behind group 0
+
+  int b3 = 0;  // buffer of K-tile kt = (kt - kt_begin) % 3
+  auto k_tile = [&](const int kt, auto chk) {
+    constexpr bool CHK = decltype(chk)::value;
+    // ---------------- LDS segment
+    read_frags(b3);
+    G8_LDS_DONE();
+    G8_BARRIER();
+    // ---------------- MFMA segment: 16 MFMA + the 6 pieces of K-tile kt + 2 + group, then the counted wait
+    const int st_kt = kt + 2 + wr;
+    const int st_b = wr ? b3 : (b3 == 0 ? 2 : b3 - 1);   // (kt + 3) % 3 = b3 for group 1, (kt + 2) % 3 for group 0
+    __builtin_amdgcn_s_setprio(1);
+    int n = 0;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          acc[mb][nq] = Mfma32<F16>::run(bfr[nq][ks], af[mb][ks], acc[mb][nq]);
+          ++n;
+          if (n == 2 || n == 4 || n == 7 || n == 10 || n == 12 || n == 15) {
+            const int pc = n == 2 ? 0 : n == 4 ? 1 : n == 7 ? 2 : n == 10 ? 3 : n == 12 ? 4 : 5;
+            G8_FENCE();
+            stage_piece(st_kt, st_b, pc >> 1, pc & 1, chk);
+            G8_FENCE();
+          }
+        }
+    __builtin_amdgcn_s_setprio(0);
+    G8_FENCE();
+    // retire everything but the pieces just issued: K-tile kt + 1 (+ group) becomes readable after the next barrier
+    if (!CHK || st_kt < kt_end) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G8_BARRIER();
+    b3 = b3 == 2 ? 0 : b3 + 1;
+  };
+  int kt = kt_begin;
+  for (; kt + 3 < kt_end; ++kt) k_tile(kt, std::false_type{});   // steady state: K-tile kt + 3 exists
+  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});
+  if (wr == 0) G8_BARRIER();  // group 0 closes the stagger
+
+  if (is_split && !split_k_reduce<2>(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
+
+  const bool wide = !((p.ldc | (p.residual ? p.ldr : 0)) & 7) && !(((uintptr_t)p.C | (uintptr_t)p.residual) & 15);
+  if (wide) {
+    if (is_split) __syncthreads();
+    store_tile_lds<F16, 2>(p, m0 + wr * 64, n0 + wc * 64, lane, smem + wave * (64 * 128), acc);
+  } else {
+    typedef TileCfg<128, 256, 64, 2, 4> CfgM;
+    store_tile<F16, CfgM>(p, m0 + wr * 64, n0 + wc * 64, lane, acc);
+  }
 }
 
 // ---------------------------------------------------------------- split-K workspaces (caller-owned)
@@ -405,6 +570,31 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8::LDS_BYTES, stream, p, sp);
   return check_launch("gemm8");
+}
+
+template <bool F16>
+static int launch_gemm8m_t(GemmParams p, bool allow_split, hipStream_t stream) {
+  p.tiles_m = (p.M + g8m::BM - 1) / g8m::BM;
+  p.tiles_n = (p.N + g8m::BN - 1) / g8m::BN;
+  auto kern = gemm8m_kernel<F16>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8m::LDS_BYTES);
+    if (e != hipSuccess) return set_error(e, "gemm8m: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  SplitArgs sp;
+  int grid = 0;
+  if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8m::BK, allow_split, &sp, &grid, stream)) return st;
+  ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8m::LDS_BYTES, stream, p, sp);
+  return check_launch("gemm8m");
+}
+
+int launch_gemm8m(const GemmParams& p, bool f16, bool split, hipStream_t stream) {
+  if ((size_t)p.M * p.lda * 2 > 0x7fffffffull || (size_t)p.N * p.ldw * 2 > 0x7fffffffull)
+    return set_error(-1, "gemm8m: operand larger than 2 GiB");
+  return f16 ? launch_gemm8m_t<true>(p, split, stream) : launch_gemm8m_t<false>(p, split, stream);
 }
 
 int launch_gemm8(const GemmParams& p, bool f16, bool split, hipStream_t stream) {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(gf8::THREADS, 2) void gemm_fp8_kernel(GemmParams p,
 #undef GF_BARRIER
 #undef GF_PHASE_SYNC
 
-  if (is_split && !split_k_reduce(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
+  if (is_split && !split_k_reduce<4>(acc, sp, unit, seg, tile_id, smem, tid, wave, lane)) return;
 
   // de-quantise: (q(x) . q(W)^T) * s_x * s_w, then the shared bf16 epilogue (bias / activation / gate / residual)
   const float sc = f.a_scale[0] * f.w_scale;

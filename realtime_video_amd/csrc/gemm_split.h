@@ -54,8 +54,10 @@ __device__ __forceinline__ bool split_unit_of_block(const SplitArgs& sp, int bid
 // device: publish this unit's partial 128x64-per-wave accumulators; the last arriver of the tile returns true with
 // the full sum in `acc` (placement-independent: the slab is a per-lane register image, the reduce is elementwise).
 // `smem` needs 4 free bytes at offset 0 (the K loop is over).  8 waves, acc = [4][2] blocks of 32x32 per wave.
-__device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[4][2], const SplitArgs& sp, int unit, int seg, int tile_id,
+template <int TM>   // 32x32 blocks per wave: TM x 2 (the 256-row kernel: 4, the 128-row kernel: 2)
+__device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[TM][2], const SplitArgs& sp, int unit, int seg, int tile_id,
                                                char* smem, int tid, int wave, int lane) {
+  constexpr int NB = TM * 2;
   // Publish with WRITE-THROUGH (sc1) 16-byte stores + a per-wave drain, then ONE relaxed agent-scope ticket: no release
   // fence.  A release fence is `buffer_wbl2`, which writes back every dirty line of the XCD's L2 - at the end of a GEMM that
   // is megabytes of other workgroups' freshly written output tiles (measured: the 16 split units of the FFN-in GEMM cost
@@ -63,12 +65,12 @@ __device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[4][2], const SplitA
   __amdgpu_buffer_rsrc_t slab =
       __builtin_amdgcn_make_buffer_rsrc((void*)(sp.slabs + (size_t)unit * SPLIT_SLAB_FLOATS), 0, SPLIT_SLAB_FLOATS * 4, 0x00020000);
 #pragma unroll
-  for (int blk = 0; blk < 8; ++blk)
+  for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x16& a = acc[blk >> 1][blk & 1];
       const f32x4 v = {a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab, (((wave * 8 + blk) * 4 + q) * 64 + lane) * 16, 0,
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slab, (((wave * NB + blk) * 4 + q) * 64 + lane) * 16, 0,
                                              /*aux: sc1*/ 16);
     }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
@@ -91,10 +93,10 @@ __device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[4][2], const SplitA
     if (s == seg) continue;
     const float4* other = (const float4*)(sp.slabs + (size_t)(unit0 + s) * SPLIT_SLAB_FLOATS);
 #pragma unroll
-    for (int blk = 0; blk < 8; ++blk)
+    for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float4 v = other[((wave * 8 + blk) * 4 + q) * 64 + lane];
+        const float4 v = other[((wave * NB + blk) * 4 + q) * 64 + lane];
         f32x16& a = acc[blk >> 1][blk & 1];
         a[4 * q] += v.x;
         a[4 * q + 1] += v.y;

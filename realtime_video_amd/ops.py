@@ -148,7 +148,7 @@ def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=a.dtype, device=a.device)
-    if tile_cfg in (0, 5, 50, 51, 52, 53):
+    if tile_cfg in (0, 5, 7, 50):
         ensure_gemm_workspace(a.device)
     _lib.call("rtv_gemm", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K,
               _ptr(bias), int(act), _ptr(gate), int(gate_stride), int(rows_per_frame), int(row_offset),

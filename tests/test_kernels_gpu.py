@@ -81,7 +81,7 @@ def _gemm_ref(a, w, bias, act, gate, rows_per_frame, residual):
     return y
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("M,N,K", [(4680, 1536, 1536), (200, 64, 256), (3, 1536, 256), (585, 4608, 1536),
                                    (4680, 256, 64)])
 def test_gemm_bias(ops, M, N, K, cfg):
@@ -126,8 +126,8 @@ def test_gemm_fp16(ops):
     assert rel_l2(out, ref) <= 1e-3
 
 
-@pytest.mark.parametrize("cfg", [0, 5])
-@pytest.mark.parametrize("M,N,K", [(4680, 5120, 1024), (4680, 13824, 512), (2400, 7680, 2048)])
+@pytest.mark.parametrize("cfg", [0, 5, 7])
+@pytest.mark.parametrize("M,N,K", [(4680, 5120, 1024), (4680, 13824, 512), (2400, 7680, 2048), (585, 5120, 5120)])
 def test_gemm_split_k_tail_round(ops, M, N, K, cfg):
     """tile_cfg 5: the tiles of the last partial round are split along K over several workgroups and reduced in-launch
     (agent-scope release/acquire + arrival counter).  Repeated launches reuse the workspace."""
@@ -139,8 +139,8 @@ def test_gemm_split_k_tail_round(ops, M, N, K, cfg):
         assert max_abs(out, ref) <= 0.05 * float(ref.float().abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
-@pytest.mark.parametrize("M,N,K", [(4680, 1536, 512), (777, 264, 64), (130, 5128, 128), (1560, 512, 192)])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("M,N,K", [(4680, 1536, 512), (777, 264, 64), (130, 5128, 128), (1560, 512, 192), (585, 1536, 320)])
 def test_gemm_epilogue_through_lds_all_fusions(ops, M, N, K, cfg):
     """Every fused epilogue (bias / GELU / SiLU / per-frame gate + residual in place / residual only) through the LDS-staged
     coalesced store path of every tile config, ragged M and N edges, K of 1..3 K-tiles (pipeline prologue / tail), and the
