@@ -127,7 +127,7 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     const long tiles_n = (p.N + 255) / 256;
     const long tiles256 = (long)((p.M + 255) / 256) * tiles_n, tiles128 = (long)((p.M + 127) / 128) * tiles_n;
     const long pad256 = (long)((p.M + 255) / 256) * 256, pad128 = (long)((p.M + 127) / 128) * 128;
-    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < pad256 * 93 || tiles256 < 256))
+    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < pad256 * 93 || tiles256 < 160))
       return launch_gemm8m(p, f16, true, stream);
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
     // along K over the idle CUs, scripts/cp_gemm_shapes.py)

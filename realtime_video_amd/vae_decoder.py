@@ -82,7 +82,7 @@ class VAEDecoderWrapper:
         self.device = torch.device(device)
         self._t = {}
         self._w = None
-        self._arena_bytes = {}
+        self._arenas = CacheArenas()
         self.row_shard = row_shard
 
     def row_range(self, h):
@@ -250,7 +250,7 @@ class VAEDecoderWrapper:
             if i == 0:
                 v = v[..., :16]
             views[i] = v.permute(3, 0, 1, 2).unsqueeze(0)   # [1, C, 2, H, W] like the reference
-        views[0]._rtv_arena = (arena, base)
+        self._arenas.register(views, arena, base, (h, w))
         return views
 
     # ------------------------------------------------------------------ forward
@@ -268,7 +268,9 @@ class VAEDecoderWrapper:
             arena = self._new_arena(h, w)
             base = (-arena.data_ptr()) % 256
         else:
-            arena, base = feat_cache[0]._rtv_arena
+            feat_cache = list(feat_cache)
+            arena, base = self._arenas.lookup(feat_cache, (h, w), lambda: self._new_arena(h, w),
+                                              lambda a, b: self._cache_views(a, b, h, w))
         n_out = 4 * T - 3 if first else 4 * T
         r0, r1 = self.row_range(h)
         pixels = torch.empty((n_out, 3, r1 - r0, 8 * w), dtype=torch.float32, device=z.device)
@@ -279,6 +281,46 @@ class VAEDecoderWrapper:
         return pixels.unsqueeze(0), cache
 
     __call__ = forward
+
+
+class CacheArenas:
+    """Owner lookup for the streaming feature caches.  The 55-slot cache list a wrapper returns is a set of VIEWS into one arena
+    allocation that the next call updates IN PLACE (the reference allocates fresh tensors per call; keep a `.clone()` of a slot
+    if you need a snapshot - it will not be overwritten, and it can be fed back).  The arena of a list is found through the
+    storage address of its first slot; a list whose slots were cloned / moved (no longer views of a known arena) gets a new
+    arena with the slot contents copied in, and a list that belongs to another frame size is refused."""
+
+    KEEP = 4
+
+    def __init__(self):
+        self._by_ptr = {}
+
+    def register(self, views, arena, base, size):
+        # The entry holds the arena, so its address cannot be reused while it is listed; only the last few streams are
+        # kept (an evicted stream that comes back takes the copy-in path below).
+        self._by_ptr[views[0].data_ptr()] = (arena, base, size)
+        while len(self._by_ptr) > self.KEEP:
+            self._by_ptr.pop(next(iter(self._by_ptr)))
+
+    def lookup(self, cache, size, new_arena, make_views):
+        """`cache` (a list, updated in place when it has to be rebuilt) -> (arena, base)."""
+        ent = self._by_ptr.get(cache[0].data_ptr())
+        if ent is not None:
+            if ent[2] != size:
+                raise ValueError(f"feature cache belongs to a {ent[2]} stream, this call is {size}")
+            return ent[0], ent[1]
+        arena = new_arena()
+        base = (-arena.data_ptr()) % 256
+        views = make_views(arena, base)       # registers the new arena
+        for i, (dst, src) in enumerate(zip(views, cache)):
+            if (dst is None) != (src is None):
+                raise ValueError(f"feature cache slot {i}: unexpected {'tensor' if dst is None else 'None'}")
+            if dst is not None:
+                if tuple(dst.shape) != tuple(src.shape):
+                    raise ValueError(f"feature cache slot {i} has shape {tuple(src.shape)}, this stream needs {tuple(dst.shape)}")
+                dst.copy_(src)
+        cache[:] = views
+        return arena, base
 
 
 class WanVAEWrapper:

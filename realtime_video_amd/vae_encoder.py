@@ -15,7 +15,7 @@ import math
 import torch
 
 from . import _lib
-from .vae_decoder import MEAN, STD, _Attn, _Conv, _Res, pack_conv_weight
+from .vae_decoder import MEAN, STD, CacheArenas, _Attn, _Conv, _Res, pack_conv_weight
 
 c_vp = ctypes.c_void_p
 c_int = ctypes.c_int
@@ -45,6 +45,7 @@ class VAEEncoderWrapper:
         self.device = torch.device(device)
         self._t = {}
         self._w = None
+        self._arenas = CacheArenas()
         if vae is not None:
             self.load_state_dict(vae.model.state_dict())
 
@@ -195,7 +196,7 @@ class VAEEncoderWrapper:
             if i == 0:
                 v = v[..., :3]
             views[i] = v.permute(3, 0, 1, 2).unsqueeze(0)   # [1, C, n, H, W] like the reference
-        views[0]._rtv_arena = (arena, base)
+        self._arenas.register(views, arena, base, (H, W))
         return views
 
     # ------------------------------------------------------------------ forward
@@ -216,7 +217,10 @@ class VAEEncoderWrapper:
             arena = self._new_arena(H, W)
             base = (-arena.data_ptr()) % 256
         else:
-            arena, base = feat_cache[0]._rtv_arena
+            if not isinstance(feat_cache, list):
+                feat_cache = list(feat_cache)
+            arena, base = self._arenas.lookup(feat_cache, (H, W), lambda: self._new_arena(H, W),
+                                              lambda a, b: self._cache_views(a, b, H, W))
         iter_ = 1 + (T - 1) // 4
         chunks = []                       # (t0, tn, first)
         offset = 1

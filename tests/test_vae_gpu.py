@@ -141,6 +141,32 @@ def test_streaming_decoder_matches_reference_golden(golden):
     assert px.shape[1] == 9 and max_abs(px.cpu(), g["pixels"][0]) <= 3e-2
 
 
+def test_cloned_feature_cache_continues_the_stream_and_foreign_cache_is_refused():
+    """The cache list is a set of views into one arena that the next call updates in place.  A snapshot of it (every
+    slot cloned, as a caller keeping state across requests would) must continue the stream bit-identically, and a cache
+    of another frame size must be refused instead of decoded against the wrong arena."""
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    dec = VAEDecoderWrapper(DEV).init_random_weights(seed=3)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    z0, z1 = (torch.randn(1, 3, 16, 8, 12, generator=g).half().to(DEV) for _ in range(2))
+    _, cache = dec(z0, *([None] * 55))
+    snap = [None if c is None else c.clone() for c in cache]
+    px_a, cache_a = dec(z1, *cache)
+    assert cache_a[0].data_ptr() == cache[0].data_ptr()          # same arena, updated in place
+    assert not torch.equal(snap[1], cache[1])                    # ... so the old list now shows the new state
+    px_b, cache_b = dec(z1, *snap)
+    assert torch.equal(px_a, px_b)
+    for a, b in zip(cache_a, cache_b):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    px_c, _ = dec(z1, *cache_b)                                  # the rebuilt list is a registered arena again
+    assert px_c.shape == px_a.shape
+    _, other = dec(torch.zeros(1, 3, 16, 8, 20, dtype=torch.float16, device=DEV), *([None] * 55))
+    with pytest.raises(ValueError):
+        dec(z1, *other)
+    with pytest.raises(ValueError):
+        dec(z1, *[None if c is None else c.clone() for c in other])
+
+
 # ------------------------------------------------------------------------------------------------ encoder
 @pytest.mark.parametrize("C,T,H,W", [(96, 4, 16, 24), (192, 1, 8, 12), (384, 2, 8, 12)])
 def test_downsample_conv2d_stride2(C, T, H, W):
