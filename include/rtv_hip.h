@@ -153,6 +153,23 @@ int rtv_sinusoidal_embedding(const void* t, void* out, int F, int dim, rtv_strea
 int rtv_patchify(const void* x, void* rows, int C, int F, int gh, int gw, rtv_stream_t stream);
 int rtv_unpatchify(const void* rows, void* x, int C, int F, int gh, int gw, rtv_stream_t stream);
 
+/* rtv_scheduler_step: the flow-matching arithmetic of one denoising step in one launch, bit-exact with the reference's
+ *   eager chains on bf16 latents [F][C][hw]:
+ *     x0    = bf16(float(double(xt) - double(sigma[i]) * double(flow))),  i = argmin |double(timesteps) - t[f]|
+ *             (WanDiffusionWrapper._convert_flow_pred_to_x0, utils/wan_wrapper.py:181-205);
+ *     noisy = bf16((1 - sigma[j]) * float(x0) + sigma[j] * float(noise)),  j = argmin |timesteps - t_next[f]| in
+ *             float32 (FlowMatchScheduler.add_noise, utils/scheduler.py:159-176).
+ *   flow / xt are read through (frame, channel) element strides with contiguous hw (the model's [C][F][hw] output needs
+ *   no permute copy); x0 / noise / noisy are contiguous.  flow == NULL: x0 is an input (add_noise alone).  t_next == NULL:
+ *   no re-noising (last step).  t / t_next: [F] of t_kind 0 float32, 1 float64, 2 int64.  timesteps / sigmas: float32
+ *   [n_table] on the device. */
+int rtv_scheduler_step(const void* flow, int64_t flow_frame_stride, int64_t flow_channel_stride,
+                       const void* xt, int64_t xt_frame_stride, int64_t xt_channel_stride,
+                       const void* t, const void* t_next, int t_kind,
+                       const void* timesteps, const void* sigmas, int n_table,
+                       void* x0, const void* noise, void* noisy,
+                       int F, int C, int hw, rtv_stream_t stream);
+
 /* rtv_silu: out = bf16(silu(x)) elementwise (time_projection's leading nn.SiLU, causal_model.py:622-623). */
 int rtv_silu(const void* x, void* out, int64_t n, rtv_stream_t stream);
 

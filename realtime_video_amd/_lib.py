@@ -46,6 +46,8 @@ SIGNATURES = {
     "rtv_sinusoidal_embedding": [c_vp, c_vp, c_int, c_int, c_vp],
     "rtv_patchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
     "rtv_unpatchify": [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp],
+    "rtv_scheduler_step": [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_int, c_vp, c_vp, c_int,
+                           c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "rtv_pixels_to_rgb8": [c_vp, c_vp, c_int, c_int, c_int, c_vp],
     "rtv_gemm_set_workspace": [c_vp, ctypes.c_size_t],
     "rtv_gemm_set_stream_workspace": [c_vp, c_vp, ctypes.c_size_t],

@@ -272,6 +272,66 @@ def unpatchify(rows, C, F, gh, gw):
     return out
 
 
+_T_KIND = {torch.float32: 0, torch.float64: 1, torch.int64: 2}
+
+
+def _frame_view(x, what):
+    """[F, C, h, w] (any frame / channel strides, contiguous h*w plane) -> (tensor, frame stride, channel stride)."""
+    if x.dtype != torch.bfloat16:
+        raise NotImplementedError(f"scheduler_step: {what} must be bf16 (the reference's inference dtype), got {x.dtype}")
+    F, C, h, w = x.shape
+    if w > 1 and x.stride(3) != 1 or h > 1 and x.stride(2) != w:
+        x = x.contiguous()
+    return x, x.stride(0), x.stride(1)
+
+
+def scheduler_step(timesteps, sigmas, flow=None, xt=None, t=None, x0=None, noise=None, t_next=None):
+    """One launch of the flow-matching step arithmetic (include/rtv_hip.h: rtv_scheduler_step) on [F, C, h, w] latents.
+    flow/xt/t -> x0 (wan_wrapper.py:181-205); x0 (computed or given)/noise/t_next -> noisy (scheduler.py:159-176).
+    Returns (x0, noisy or None)."""
+    src = flow if flow is not None else x0
+    _gpu(src, timesteps, sigmas)
+    F, C, h, w = src.shape
+    if timesteps.dtype != torch.float32 or sigmas.dtype != torch.float32 or timesteps.numel() != sigmas.numel():
+        raise ValueError("scheduler_step: timesteps / sigmas must be float32 tables of one length")
+    tk = None
+    for tt in (t, t_next):
+        if tt is not None:
+            _gpu(tt)
+            if tt.dtype not in _T_KIND or tt.numel() != F or not tt.is_contiguous():
+                raise ValueError(f"scheduler_step: timestep must be a contiguous [F] float32/float64/int64 tensor, got "
+                                 f"{tt.dtype} {tuple(tt.shape)}")
+            if tk is not None and tk != _T_KIND[tt.dtype]:
+                raise ValueError("scheduler_step: t and t_next must share a dtype")
+            tk = _T_KIND[tt.dtype]
+    fs = fc = xs = xc = 0
+    if flow is not None:
+        _gpu(xt)
+        if xt.shape != flow.shape:
+            raise ValueError(f"scheduler_step: flow {tuple(flow.shape)} vs xt {tuple(xt.shape)}")
+        flow, fs, fc = _frame_view(flow, "flow")
+        xt, xs, xc = _frame_view(xt, "xt")
+        x0 = torch.empty((F, C, h, w), dtype=torch.bfloat16, device=src.device)
+    else:
+        if x0.dtype != torch.bfloat16:
+            raise NotImplementedError("scheduler_step: x0 must be bf16")
+        x0 = x0.contiguous()
+    noisy = None
+    if t_next is not None:
+        _gpu(noise)
+        if noise.dtype != torch.bfloat16 or noise.shape != x0.shape:
+            raise ValueError("scheduler_step: noise must be bf16 of the latent shape")
+        noise = noise.contiguous()
+        noisy = torch.empty_like(x0)
+    _lib.call("rtv_scheduler_step", _ptr(flow) if flow is not None else None, fs, fc,
+              _ptr(xt) if flow is not None else None, xs, xc, _ptr(t) if t is not None else None,
+              _ptr(t_next) if t_next is not None else None, tk if tk is not None else 0,
+              _ptr(timesteps), _ptr(sigmas), timesteps.numel(), _ptr(x0),
+              _ptr(noise) if noise is not None else None, _ptr(noisy) if noisy is not None else None,
+              F, C, h * w, _stream())
+    return x0, noisy
+
+
 def pixels_to_rgb8(pixels, out=None):
     """Decoder pixels float32 [..., 3, H, W] in [-1, 1] -> uint8 [..., H, W, 3] (rtv_pixels_to_rgb8): the reference's
     host-side normalisation + to_pil_image byte conversion (release_server.py:984, :972) done on the GPU."""

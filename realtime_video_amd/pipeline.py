@@ -148,16 +148,20 @@ class CausalInferencePipeline:
             noisy_input = noise[:, lo:lo + cur]
             for index, current_timestep in enumerate(steps):
                 timestep = torch.ones([batch_size, cur], device=noise.device, dtype=torch.int64) * current_timestep
-                _, denoised_pred = self.generator(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
-                                                  timestep=timestep, kv_cache=self.kv_cache1,
-                                                  crossattn_cache=self.crossattn_cache,
-                                                  current_start=current_start_frame * self.frame_seq_length)
+                renoise = None
                 if index < len(steps) - 1:
-                    next_timestep = steps[index + 1]
-                    noisy_input = self.scheduler.add_noise(
-                        denoised_pred.flatten(0, 1), self._randn_like(denoised_pred.flatten(0, 1)),
-                        next_timestep * torch.ones([batch_size * cur], device=noise.device, dtype=torch.long)
-                    ).unflatten(0, denoised_pred.shape[:2])
+                    # the re-noising draw (causal_inference.py:209) does not depend on the forward: drawn first so that x0
+                    # and add_noise are one launch (the forward itself consumes no random numbers)
+                    shape = (batch_size * cur,) + tuple(noisy_input.shape[2:])
+                    like = torch.empty(shape, dtype=torch.bfloat16, device=noise.device)
+                    renoise = (self._randn_like(like),
+                               steps[index + 1] * torch.ones([batch_size * cur], device=noise.device, dtype=torch.long))
+                res = self.generator(noisy_image_or_video=noisy_input, conditional_dict=conditional_dict,
+                                     timestep=timestep, kv_cache=self.kv_cache1, crossattn_cache=self.crossattn_cache,
+                                     current_start=current_start_frame * self.frame_seq_length, renoise=renoise)
+                denoised_pred = res[1]
+                if renoise is not None:
+                    noisy_input = res[2]
             output[:, current_start_frame:current_start_frame + cur] = denoised_pred
             context_timestep = torch.ones_like(timestep) * self.context_noise
             self.generator(noisy_image_or_video=denoised_pred, conditional_dict=conditional_dict,

@@ -6,6 +6,11 @@ step of the block loop synchronises with the host (release_server.py:555-560).""
 import torch
 
 
+def _ops():
+    from . import ops   # deferred: the schedule tables are usable without the kernel library
+    return ops
+
+
 class FlowMatchScheduler:
     def __init__(self, num_inference_steps=100, num_train_timesteps=1000, shift=3.0, sigma_max=1.0,
                  sigma_min=0.003 / 1.002, inverse_timesteps=False, extra_one_step=False, reverse_sigmas=False):
@@ -40,6 +45,11 @@ class FlowMatchScheduler:
         return self.sigmas[idx].reshape(-1, 1, 1, 1)
 
     def add_noise(self, original_samples, noise, timestep):
+        if (noise.is_cuda and noise.ndim == 4 and noise.dtype == torch.bfloat16 and original_samples.dtype == torch.bfloat16
+                and original_samples.shape == noise.shape and timestep.ndim == 1 and timestep.dtype in _ops()._T_KIND):
+            self.to(noise.device)   # one launch: lookup + blend (csrc/scheduler.hip), same roundings as the chain below
+            return _ops().scheduler_step(self.timesteps, self.sigmas, x0=original_samples, noise=noise,
+                                         t_next=timestep.to(noise.device).contiguous())[1]
         sigma = self._sigma_of(timestep, noise.device)
         return ((1 - sigma) * original_samples + sigma * noise).type_as(noise)
 

@@ -266,17 +266,19 @@ class GenerationSession:
         denoised_pred = None
         for index, current_timestep in enumerate(steps):
             timestep = torch.ones([1, nfpb], device=self.gpu, dtype=torch.int64) * current_timestep
-            _, denoised_pred = models.transformer(
+            renoise = None
+            if index < len(steps) - 1:
+                # release_server.py:688-694; the draw does not depend on the forward, so it is made first and x0 +
+                # add_noise run as one launch behind the model
+                renoise = (self._randn((nfpb,) + tuple(noisy_input.shape[2:])),
+                           steps[index + 1] * torch.ones([nfpb], device=self.gpu, dtype=torch.long))
+            res = models.transformer(
                 noisy_image_or_video=noisy_input, conditional_dict=self.conditional_dict, timestep=timestep,
                 kv_cache=pipe.kv_cache1, crossattn_cache=pipe.crossattn_cache,
-                current_start=start * pipe.frame_seq_length)
-            if index < len(steps) - 1:
-                next_timestep = steps[index + 1]
-                flat = denoised_pred.flatten(0, 1)
-                noisy_input = pipe.scheduler.add_noise(
-                    flat, self._randn(flat.shape),
-                    next_timestep * torch.ones([nfpb], device=self.gpu, dtype=torch.long)
-                ).unflatten(0, denoised_pred.shape[:2])
+                current_start=start * pipe.frame_seq_length, renoise=renoise)
+            denoised_pred = res[1]
+            if renoise is not None:
+                noisy_input = res[2]
         self.all_latents[:, self.current_start_frame:self.current_start_frame + nfpb] = denoised_pred
         self.last_pred = denoised_pred
         pixels = None

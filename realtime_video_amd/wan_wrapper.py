@@ -4,6 +4,7 @@ crossattn_cache, current_start)` -> `(flow_pred, pred_x0)`, flow->x0 conversion 
 (:181-205), scheduler binding (:148-151, :303-323)."""
 import torch
 
+from . import ops
 from .causal_model import CausalWanModel
 from .scheduler import FlowMatchScheduler
 
@@ -24,23 +25,43 @@ class WanDiffusionWrapper:
     def get_scheduler(self):
         return self.scheduler
 
+    @staticmethod
+    def _kernel_ok(*tensors):
+        """The one-launch scheduler kernel covers the inference case: bf16 [F, C, h, w] latents on the GPU."""
+        return all(t.is_cuda and t.dtype == torch.bfloat16 and t.ndim == 4 for t in tensors)
+
     def _convert_flow_pred_to_x0(self, flow_pred, xt, timestep):
-        dt = flow_pred.dtype
         sch = self.scheduler.to(flow_pred.device)
+        if self._kernel_ok(flow_pred, xt) and timestep.dtype in ops._T_KIND:
+            return ops.scheduler_step(sch.timesteps, sch.sigmas, flow=flow_pred, xt=xt,
+                                      t=timestep.to(flow_pred.device).contiguous())[0]
+        dt = flow_pred.dtype
         fp, x, sig, ts = flow_pred.double(), xt.double(), sch.sigmas.double(), sch.timesteps.double()
         idx = torch.argmin((ts.unsqueeze(0) - timestep.to(flow_pred.device).unsqueeze(1)).abs(), dim=1)
         return (x - sig[idx].reshape(-1, 1, 1, 1) * fp).to(dt)
 
     def forward(self, noisy_image_or_video, conditional_dict, timestep, kv_cache=None, crossattn_cache=None,
-                current_start=None, cache_start=None, **unused):
+                current_start=None, cache_start=None, renoise=None, **unused):
+        """`renoise=(noise[B*F,16,h,w], next_timestep[B*F])` (not in the reference signature): also return
+        scheduler.add_noise(x0, noise, next_timestep) as a third value, computed in the same launch as x0 - the
+        denoising loops of release_server.py:669-694 / causal_inference.py:187-212 call the two back to back."""
         if kv_cache is None:
             raise NotImplementedError("non-cached (training / bidirectional) forwards are out of scope")
         flow = self.model(noisy_image_or_video.permute(0, 2, 1, 3, 4), t=timestep,
                           context=conditional_dict["prompt_embeds"], seq_len=self.seq_len, kv_cache=kv_cache,
                           crossattn_cache=crossattn_cache, current_start=current_start,
                           cache_start=cache_start).permute(0, 2, 1, 3, 4)
-        x0 = self._convert_flow_pred_to_x0(flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1),
-                                           timestep.flatten(0, 1)).unflatten(0, flow.shape[:2])
-        return flow, x0
+        fl, xt, ts = flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1), timestep.flatten(0, 1)
+        if renoise is None:
+            return flow, self._convert_flow_pred_to_x0(fl, xt, ts).unflatten(0, flow.shape[:2])
+        noise, t_next = renoise
+        sch = self.scheduler.to(flow.device)
+        if self._kernel_ok(fl, xt, noise) and ts.dtype in ops._T_KIND and t_next.dtype == ts.dtype:
+            x0, noisy = ops.scheduler_step(sch.timesteps, sch.sigmas, flow=fl, xt=xt, t=ts.contiguous(), noise=noise,
+                                           t_next=t_next.to(flow.device).contiguous())
+        else:
+            x0 = self._convert_flow_pred_to_x0(fl, xt, ts)
+            noisy = sch.add_noise(x0, noise, t_next)
+        return flow, x0.unflatten(0, flow.shape[:2]), noisy.unflatten(0, flow.shape[:2])
 
     __call__ = forward

@@ -624,3 +624,83 @@ def test_qk_norm_rope_cache_ring_write(ops):
     assert torch.equal(ring[mask.to(DEV)], base[mask.to(DEV)])
     with pytest.raises(RuntimeError):
         ops.qk_norm_rope_cache(qkv, ring[:, 0], ring[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5, ring=(lo, 100, 3))
+
+
+# ----------------------------------------------------------------------------------------- scheduler step (one launch)
+def _eager_x0(sch, flow, xt, t):
+    """The reference's eager chain (utils/wan_wrapper.py:181-205) evaluated with torch ops."""
+    fp, x, sig, ts = flow.double(), xt.double(), sch.sigmas.double(), sch.timesteps.double()
+    idx = torch.argmin((ts.unsqueeze(0) - t.unsqueeze(1)).abs(), dim=1)
+    return (x - sig[idx].reshape(-1, 1, 1, 1) * fp).to(flow.dtype)
+
+
+def _eager_add_noise(sch, x0, noise, t):
+    """utils/scheduler.py:159-176 with torch ops."""
+    idx = torch.argmin((sch.timesteps.unsqueeze(0) - t.unsqueeze(1)).abs(), dim=1)
+    sigma = sch.sigmas[idx].reshape(-1, 1, 1, 1)
+    return ((1 - sigma) * x0 + sigma * noise).type_as(noise)
+
+
+def test_scheduler_step_is_bit_exact_with_the_reference_golden(golden, ops):
+    """x0 and add_noise minted from the reference (oracle/make_golden.py) - integer-exact comparison."""
+    from realtime_video_amd.scheduler import FlowMatchScheduler
+    from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
+    g = golden("ops.pt")
+    sch = FlowMatchScheduler(shift=5.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    sch.to(DEV)
+    a, b, t = g["an_x0"].to(DEV), g["an_noise"].to(DEV), g["an_t"].to(DEV)
+    assert torch.equal(sch.add_noise(a, b, t).cpu(), g["an_out"])                 # kernel path (GPU bf16 4-D)
+    assert torch.equal(sch.add_noise(a, b, t.long()).cpu(), sch.add_noise(a.cpu(), b.cpu(), t.long().cpu()))
+    wr = WanDiffusionWrapper.__new__(WanDiffusionWrapper)
+    wr.scheduler = sch
+    assert torch.equal(wr._convert_flow_pred_to_x0(a, b, t).cpu(), g["x0_out"])
+    x0, noisy = ops.scheduler_step(sch.timesteps, sch.sigmas, flow=a, xt=b, t=t, noise=a, t_next=t)
+    assert torch.equal(x0.cpu(), g["x0_out"])
+    assert torch.equal(noisy, _eager_add_noise(sch, x0, a, t))
+
+
+@pytest.mark.parametrize("tdtype", [torch.float32, torch.int64, torch.float64])
+def test_scheduler_step_matches_the_eager_chain_bitwise_at_full_size(ops, tdtype):
+    """3 x 16 x 60 x 104 latents, the model's [C, F, h, w] output read through strides, per-frame timesteps that differ,
+    ties of the nearest-timestep search included (t halfway between two table entries)."""
+    from realtime_video_amd.scheduler import FlowMatchScheduler
+    sch = FlowMatchScheduler(shift=8.0, sigma_min=0.0, extra_one_step=True)
+    sch.set_timesteps(1000, training=True)
+    sch.to(DEV)
+    F, C, h, w = 3, 16, 60, 104
+    out_cf = _randn(C, F, h, w, seed=3)                       # what the DiT returns
+    flow = out_cf.permute(1, 0, 2, 3)                         # [F, C, h, w] view, channel stride F*h*w
+    big = _randn(7, C, h, w, seed=4)
+    xt = big[2:5]                                             # a slice of the session's noise buffer
+    noise = _randn(F, C, h, w, seed=5)
+    tab = sch.timesteps
+    mid = ((tab[10].double() + tab[11].double()) / 2).item()
+    for t_list, tn_list in [([1000.0, 750.0, 500.0], [750.0, 500.0, 250.0]), ([mid, 0.0, 999.0], [3.0, mid, 1000.0]),
+                            ([tab[500].item()] * 3, [tab[999].item()] * 3)]:
+        t = torch.tensor(t_list, dtype=torch.float64).to(tdtype).to(DEV)
+        tn = torch.tensor(tn_list, dtype=torch.float64).to(tdtype).to(DEV)
+        x0, noisy = ops.scheduler_step(sch.timesteps, sch.sigmas, flow=flow, xt=xt, t=t, noise=noise, t_next=tn)
+        ref_x0 = _eager_x0(sch, flow, xt, t)
+        assert torch.equal(x0, ref_x0)
+        assert torch.equal(noisy, _eager_add_noise(sch, ref_x0, noise, tn))
+        x0_only, none = ops.scheduler_step(sch.timesteps, sch.sigmas, flow=flow, xt=xt, t=t)
+        assert none is None and torch.equal(x0_only, ref_x0)
+        _, noisy_only = ops.scheduler_step(sch.timesteps, sch.sigmas, x0=ref_x0, noise=noise, t_next=tn)
+        assert torch.equal(noisy_only, noisy)
+
+
+def test_scheduler_step_refuses_what_it_does_not_cover(ops):
+    from realtime_video_amd.scheduler import FlowMatchScheduler
+    sch = FlowMatchScheduler(shift=8.0, sigma_min=0.0, extra_one_step=True).to(DEV)
+    a = _randn(3, 16, 8, 12)
+    t = torch.full((3,), 500.0, device=DEV)
+    with pytest.raises(NotImplementedError):
+        ops.scheduler_step(sch.timesteps, sch.sigmas, flow=a.float(), xt=a.float(), t=t)
+    with pytest.raises(ValueError):
+        ops.scheduler_step(sch.timesteps, sch.sigmas, flow=a, xt=a, t=t[:2])
+    with pytest.raises(RuntimeError):
+        ops.scheduler_step(sch.timesteps.cpu(), sch.sigmas.cpu(), flow=a.cpu(), xt=a.cpu(), t=t.cpu())
+    # float32 latents keep the eager chain (still on the GPU)
+    out = sch.add_noise(a.float(), a.float(), t)
+    assert out.dtype == torch.float32
