@@ -71,7 +71,10 @@ int rtv_attn_fwd_win(const void* q, const void* k, const void* v, void* o,
                      int64_t o_batch_stride, int64_t o_row_stride,
                      float scale, int causal_block, int q_offset, int dtype, rtv_stream_t stream);
 /* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
- * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  A tuning knob for A/B measurements. */
+ * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  256-row launches over >= 1024 keys run the
+ * four-phase kernel (K/V by LDS DMA, fragments read a phase ahead of their MFMAs, the two wave groups one phase apart),
+ * shorter windows the lockstep one; 81 / 82 force the lockstep / four-phase schedule.  All variants compute every row with
+ * the same arithmetic in the same order (bit-identical outputs).  A tuning knob for A/B measurements and tests. */
 int rtv_attn_set_waves(int waves);
 
 /* ---- K4: projection GEMM with fused epilogue ---------------------------------------------

@@ -35,6 +35,7 @@ struct AttnParams {
   // two-segment key window (ring-indexed rolling KV cache, causal_model.py:363-379 without the shift copy): key v of the
   // window is cache row v for v < n0 and row v + delta for v >= n0 (rows relative to k / v); n0 == Lkv: one segment.
   int n0, delta;
+  int off0;   // four-phase kernel only: keys v < n0 are cache rows v + off0 (its k / v point at the lowest row of the window)
 };
 
 constexpr int ATT_D = 128;
@@ -351,6 +352,422 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
+
+// =====================================================================================================================
+// Four-phase ping-pong schedule (8 waves, 256 query rows): the kernel the 256-row launches use.
+//
+// Phase trace of the lockstep loop above (profiles/r02_attn_phase_trace_v1.log): a tile period of 4300 cycles for the
+// 2 x 1024 MFMA cycles a SIMD owes its two waves - both waves of a SIMD are in the same phase at the same time, and every
+// MFMA waits for its own ds_read.  The earlier two-segment ping-pong (profiles/r02_attn_pingpong_experiment.log) moved the
+// waves apart but kept the reads inside the MFMA segment (60-68 cycles per MFMA) and paid 750-950 cycles per tile for the
+// register-staged global -> LDS copies.  Here:
+//   * K / V tiles go HBM/L2 -> LDS by DMA (`buffer_load ... lds`, 16 B per lane, source-side swizzle so the LDS image is
+//     the same XOR layout the fragment reads want), two tiles ahead in a 3-slot ring per operand, retired by ONE counted
+//     `s_waitcnt vmcnt(4)` per issue point a whole tile before the data is read - no staging registers, no ds_write;
+//   * a tile is four phases per wave, separated by s_barrier:
+//         LK  read the 16 K fragments of the tile into registers (16 ds_read_b128), issue the K DMA of tile j+2
+//         QK  16 MFMAs on register operands                                  S^T = K . Q^T
+//         LV  read the 16 V^T fragments (32 transpose reads) into the SAME registers, issue the V DMA of tile j+2,
+//             mask + online softmax of S^T -> P^T (VALU, beside the partner's MFMAs)
+//         PV  16 MFMAs on register operands                                  O^T += V^T . P^T
+//     waves 4-7 run ONE phase behind waves 0-3, so in every phase one wave of each SIMD is in a matrix phase and its
+//     partner in a load/VALU phase:
+//         phase 4j: g0 LK(j)  g1 PV(j-1) | 4j+1: g0 QK(j)  g1 LK(j) | 4j+2: g0 LV(j)  g1 QK(j) | 4j+3: g0 PV(j)  g1 LV(j)
+//   * ring hazards: K(j+2) lands in the slot of K(j-1), last read in phase 4j-3; V(j+2) in the slot of V(j-1), last read in
+//     phase 4j-1; a tile's DMA is complete (issuer's vmcnt + the phase barrier) >= 3 phases before its first read.
+// Registers: Q^T 32 + O^T 64 + S^T 32 + P^T 16 + fragments 64 = 208 of the 256 a wave has at two waves per SIMD.
+constexpr int ATT_NB = 3;   // ring slots per operand
+#ifndef ATT_DMA_IN_MFMA
+#define ATT_DMA_IN_MFMA 0   // 1: K / V DMA issued inside the QK / PV phases instead of the load phases (measured: -3 %)
+#endif
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// Transpose read as inline asm: the builtin carries no pointer information, so behind a pending LDS DMA the compiler's
+// wait-count pass puts `s_waitcnt vmcnt(0)` in front of it (a whole DMA latency per tile).  The asm form is invisible to
+// that pass - the consumer side waits with lds_wait_frags() below.
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_tr_read_at(uint32_t lds_addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+  return r;
+}
+// s_waitcnt lgkmcnt(0) that the fragment registers depend on (so no consumer can be scheduled above it)
+__device__ __forceinline__ void lds_wait_frags(u32x4 (&f)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+  asm volatile("" : "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
+}
+// the value of lane ^ 32 without the LDS crossbar (ds_bpermute would queue behind the transpose reads in flight)
+__device__ __forceinline__ float xor32_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lanes: [lo, lo], [hi, hi]}
+  return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+
+#ifdef RTV_ATTN_TRACE
+#define ATT_STAMP8(i)                                                                   \
+  do {                                                                                  \
+    if (tr_on && j >= 20 && j < 24) {                                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                \
+      const unsigned t_ = (unsigned)__builtin_readcyclecounter();                       \
+      if (lane == 0) tr_lds[(j - 20) * 8 + (i)] = t_;   /* LDS, not global: stores would count in vmcnt */ \
+      __builtin_amdgcn_sched_barrier(0);                                                \
+    }                                                                                   \
+  } while (0)
+#else
+#define ATT_STAMP8(i)
+#endif
+
+template <bool F16>
+__global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
+  constexpr int ATT_QT = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // smem: K[ATT_NB][16 KiB] | V[ATT_NB][16 KiB]
+  char* const sK = smem;
+  char* const sV = smem + ATT_NB * ATT_TILE_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;   // 0: waves 0-3, 1: waves 4-7 (one phase behind)
+  const int l31 = lane & 31, g = lane >> 5;
+
+  int bh, qt;
+  {
+    const int nbh = p.B * p.H;
+    const int bid = blockIdx.x;
+    if (nbh % 8 == 0) {   // all q tiles of a head on ONE XCD (block b runs on XCD b % 8): its K/V stream stays in that L2
+      int xcd = bid & 7, slot = bid >> 3;
+      bh = xcd + 8 * (slot / p.n_qtiles);
+      qt = slot % p.n_qtiles;
+    } else {
+      bh = bid / p.n_qtiles;
+      qt = bid % p.n_qtiles;
+    }
+  }
+  const int b = bh / p.H, h = bh % p.H;
+  const int q0 = qt * ATT_QT;
+  const uint16_t* qb = p.q + (size_t)b * p.q_bs + (size_t)h * ATT_D;
+  const uint16_t* kb = p.k + (size_t)b * p.k_bs + (size_t)h * ATT_D;
+  const uint16_t* vb = p.v + (size_t)b * p.v_bs + (size_t)h * ATT_D;
+  uint16_t* ob = p.o + (size_t)b * p.o_bs + (size_t)h * ATT_D;
+
+  // ---- key-prefix limits (block-causal rule kv < ends[q], causal_model.py:134-136)
+  const int q_row = q0 + wave * ATT_QW + l31;
+  const int q_row_c = min(q_row, p.Lq - 1);
+  int kv_lim = p.Lkv, wave_min_lim = p.Lkv, wg_max_lim = p.Lkv;
+  if (p.causal_block > 0) {
+    const int cb = p.causal_block;
+    kv_lim = min(p.Lkv, ((p.q_offset + q_row_c) / cb + 1) * cb);
+    int first = min(q0 + wave * ATT_QW, p.Lq - 1);
+    wave_min_lim = min(p.Lkv, ((p.q_offset + first) / cb + 1) * cb);
+    int last = min(q0 + ATT_QT - 1, p.Lq - 1);
+    wg_max_lim = min(p.Lkv, ((p.q_offset + last) / cb + 1) * cb);
+  }
+  const int ntiles = (wg_max_lim + ATT_KT - 1) / ATT_KT;
+
+  // ---- DMA staging: wave w moves tile rows 8w .. 8w+7 of K and of V, two 1-KiB pieces (4 rows) each.  Lane l lands at byte
+  //      16 l of the piece = row (l >> 4), chunk position (l & 15); it fetches the chunk that belongs there:
+  //      K: position = chunk ^ (row & 15);  V: position = chunk ^ ((row & 3) << 2)   (the layouts of the fragment reads).
+  //      Full tiles: per-lane byte offset fixed for the whole kernel + a uniform tile offset (SGPR); the ragged last tile and
+  //      the tile that straddles the two ranges of a ring window compute a per-lane row.
+  const __amdgpu_buffer_rsrc_t rsrcK = __builtin_amdgcn_make_buffer_rsrc((void*)kb, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcV = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, 0x7fffffff, 0x00020000);
+  const int st_row = wave * 8 + (lane >> 4);   // tile row of piece 0 (piece 1: + 4)
+  const int st_cp = lane & 15;
+  const int k_rs = (int)p.k_rs, v_rs = (int)p.v_rs;
+  int k_ch[2], v_ch[2];
+  uint32_t k_fast[2], v_fast[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = st_row + 4 * i;
+    k_ch[i] = (st_cp ^ (r & 15)) * 8;
+    v_ch[i] = (st_cp ^ ((r & 3) << 2)) * 8;
+    k_fast[i] = (uint32_t)(r * k_rs + k_ch[i]) * 2u;
+    v_fast[i] = (uint32_t)(r * v_rs + v_ch[i]) * 2u;
+  }
+  auto stage = [&](const __amdgpu_buffer_rsrc_t& rsrc, char* ring, int j, int rs, const uint32_t (&fast)[2],
+                   const int (&ch)[2]) {
+    const int row0 = j * ATT_KT;
+    char* const dst = ring + (j % ATT_NB) * ATT_TILE_BYTES + wave * (8 * 256);
+    const bool in0 = row0 + ATT_KT <= p.n0;
+    if (in0 || (row0 >= p.n0 && row0 + ATT_KT <= p.Lkv)) {
+      const uint32_t so = (uint32_t)((row0 + (in0 ? p.off0 : p.delta)) * rs) * 2u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (RTV_LDS void*)(dst + i * 1024), 16, fast[i], so, 0, 0);
+    } else {   // (also every tile past the end: clamped rows into a slot nobody reads - the wait counts stay uniform)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int kv = min(row0 + st_row + 4 * i, p.Lkv - 1);
+        kv += kv >= p.n0 ? p.delta : p.off0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (RTV_LDS void*)(dst + i * 1024), 16,
+                                                 (uint32_t)(kv * rs + ch[i]) * 2u, 0, 0, 0);
+      }
+    }
+  };
+  auto stage_k = [&](int j) { stage(rsrcK, sK, j, k_rs, k_fast, k_ch); };
+  auto stage_v = [&](int j) { stage(rsrcV, sV, j, v_rs, v_fast, v_ch); };
+
+  // ---- prologue: tiles 0 and 1 of both operands, Q^T fragments (MFMA B operand): lane holds Q[q][dc*16 + g*8 .. +8]
+  stage_k(0);
+  stage_v(0);
+  stage_k(1);
+  stage_v(1);
+  u32x4 qf[8];
+  {
+    const uint16_t* qp = qb + (size_t)q_row_c * p.q_rs + g * 8;
+#pragma unroll
+    for (int dc = 0; dc < 8; ++dc) qf[dc] = *(const u32x4*)(qp + dc * 16);
+  }
+
+  // ---- per-lane LDS read addresses (slot 0); K operand (A): row = kbk*32 + l31, chunk = (dc*2 + g) ^ (row & 15)
+  const char* k_rd[8];
+#pragma unroll
+  for (int dc = 0; dc < 8; ++dc) k_rd[dc] = sK + l31 * 256 + (((dc * 2 + g) ^ (l31 & 15)) << 4);
+  // V^T operand (A) via transpose read: 16-lane group gathers a [4 keys][16 dims] block
+  const int i16 = lane & 15, h16 = (lane >> 4) & 1;
+  uint32_t v_rd32[4];   // 32-bit LDS addresses (the transpose reads are inline asm)
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    v_rd32[db] = (uint32_t)(uintptr_t)(RTV_LDS const char*)(sV + (4 * g + (i16 >> 2)) * 256 + h16 * 32 + (i16 & 3) * 8 +
+                                                            ((db ^ (i16 >> 2)) << 6));
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -1e30f;  // reference point of the exponentials (>= running max - RESCALE_SLACK), log2 domain
+  float l_run = 0.f;     // this lane's partial row sum
+  const float c = p.scale_log2e;
+  const f32x2 c2 = {c, c};
+  constexpr float RESCALE_SLACK = 8.f;   // lazy rescaling, see the lockstep kernel
+
+  f32x16 sacc[2];   // S^T of the tile in flight (two 32-key blocks)
+  u32x4 pf[2][2];   // P^T: [kv block][k-step], 8 x 16-bit = the lane's own 8 keys of that 16-key step
+  u32x4 frag[16];   // K fragments [dc][kbk] during LK/QK, V^T fragments [kbk][s][db] during LV/PV
+  f32x2 ps2 = {0.f, 0.f};   // row-sum partials of the tile in flight
+  // one step of the exponentials: keys 2t, 2t+1 of 32-key block kbk -> half a P^T register
+  auto exp_step = [&](auto kc, auto tc) {
+    constexpr int kbk = decltype(kc)::value, t = decltype(tc)::value;
+    const f32x2 nm2 = {-m_run, -m_run};
+    f32x2 x = {sacc[kbk][2 * t], sacc[kbk][2 * t + 1]};
+    x = __builtin_elementwise_fma(x, c2, nm2);  // v_pk_fma_f32
+#ifdef ATT_LAB_T3   // timing experiment: no exponentials
+    f32x2 e = x;
+#else
+    f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+#endif
+    ps2 += e;                                   // v_pk_add_f32
+    pf[kbk][t >> 2][t & 3] = pack2<F16>(e[0], e[1]);
+  };
+
+#ifdef RTV_ATTN_TRACE
+  const bool tr_on = g_attn_trace != nullptr && (wave == 0 || wave == 7) && blockIdx.x < 512;
+  unsigned* const tr_dst = g_attn_trace + ((size_t)(blockIdx.x & 511) * 2 + (wave == 0 ? 0 : 1)) * 32;
+  unsigned* const tr_lds = (unsigned*)(smem + 2 * ATT_NB * ATT_TILE_BYTES) + (wave == 0 ? 0 : 32);   // 256 B behind the rings
+#endif
+#define PP_BARRIER()                        \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (grp) PP_BARRIER();   // the stagger
+
+  for (int j = 0; j < ntiles; ++j) {
+    const int slot_off = (j % ATT_NB) * ATT_TILE_BYTES;
+    // ---------------- LK
+    ATT_STAMP8(0);
+#if !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA
+    stage_k(j + 2);
+#endif
+#ifdef ATT_LAB_T5
+    stage_v(j + 2);
+#endif
+#pragma unroll
+    for (int dc = 0; dc < 8; ++dc)
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) frag[dc * 2 + kbk] = *(const u32x4*)(k_rd[dc] + slot_off + kbk * 32 * 256);
+#if ATT_DMA_IN_MFMA
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // everything but the youngest issue point (V(j+1)): K(j+1) has landed
+#else
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the two youngest issue points: K(j+1) has landed
+#endif
+    ATT_STAMP8(1);
+    PP_BARRIER();
+    // ---------------- QK: S^T = K . Q^T (two independent accumulator chains)
+    ATT_STAMP8(2);
+#pragma unroll
+    for (int dc = 0; dc < 8; ++dc)
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) {
+        if (dc == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          sacc[kbk] = mfma32<F16>(frag[kbk], qf[0], z);
+        } else {
+          sacc[kbk] = mfma32<F16>(frag[dc * 2 + kbk], qf[dc], sacc[kbk]);
+        }
+#if ATT_DMA_IN_MFMA
+        if (dc == 3 && kbk == 1) {   // the K DMA of tile j+2 in the shadow of the matrix pipe
+          __builtin_amdgcn_sched_barrier(0);
+          stage_k(j + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
+      }
+    ATT_STAMP8(3);
+    PP_BARRIER();
+    // ---------------- LV: V^T fragments, V DMA, mask + online softmax
+    // The 32 transpose reads are LDS-throughput bound when the four waves of a group issue them together (2 LDS cycles each,
+    // ~256 cycles for the group): they are issued in small groups BETWEEN the pieces of the softmax, so the VALU work runs
+    // while the LDS serves them instead of behind a full read queue.
+    ATT_STAMP8(4);
+#if !defined(ATT_LAB_T5) && !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA   // (T5: V DMA issued in LK; T6: no DMA in the loop)
+    stage_v(j + 2);
+#endif
+    uint32_t va[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) va[db] = v_rd32[db] + (uint32_t)slot_off;
+    auto rd_v = [&](auto ic) {   // fragment idx = (kbk*2 + s)*4 + db
+#ifndef ATT_LAB_T4   // (T4, timing experiment: no V reads - PV runs on the K fragments)
+      constexpr int idx = decltype(ic)::value;
+      constexpr int off = ((idx >> 3) * 32 + ((idx >> 2) & 1) * 16) * 256;
+      const u32x2 lo = lds_tr_read_at<off>(va[idx & 3]);             // keys +0..3  (this lane group's first quad)
+      const u32x2 hi = lds_tr_read_at<off + 8 * 256>(va[idx & 3]);   // keys +8..11
+      frag[idx] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+#endif
+    };
+#define LV_FENCE() __builtin_amdgcn_sched_barrier(0)
+    rd_v(IntC<0>{});
+    rd_v(IntC<1>{});
+    LV_FENCE();
+    if ((j + 1) * ATT_KT > wave_min_lim) {   // mask: only on tiles that cross a limit of this wave
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int kv = j * ATT_KT + kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+          if (kv >= kv_lim) sacc[kbk][r] = -INFINITY;
+        }
+    }
+    {
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+      LV_FENCE();
+      rd_v(IntC<2>{});
+      rd_v(IntC<3>{});
+      LV_FENCE();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+      LV_FENCE();
+      rd_v(IntC<4>{});
+      rd_v(IntC<5>{});
+      LV_FENCE();
+      mx = xor32_max(mx);
+      const float m_cand = fmaxf(m_run, mx * c);
+      const bool need = m_cand - m_run > RESCALE_SLACK;
+      if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        // wave-uniform branch, per-row decision: rows that do not need it multiply by exp2(0) = 1 exactly, so a row's
+        // arithmetic never depends on which other rows share its wave (token-sharded == unsharded, bit for bit)
+        const float m_new = need ? m_cand : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
+      LV_FENCE();
+      rd_v(IntC<6>{});
+      rd_v(IntC<7>{});
+      LV_FENCE();
+      // exponentials of the first 32-key block here; those of the second block run inside the PV phase, between the
+      // MFMAs of the first block (the wave's own issue slots while the matrix pipe works)
+      static_for<0, 8>([&](auto ic) {
+        constexpr int t = decltype(ic)::value;
+        exp_step(IntC<0>{}, ic);
+        LV_FENCE();
+        rd_v(IntC<8 + t>{});
+        LV_FENCE();
+      });
+    }
+#undef LV_FENCE
+    // the first half of P^T is complete HERE: without this the compiler sinks exponentials / packs below the barrier, into
+    // the matrix phase (sched_barrier does not stop its code sinking)
+    asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(ps2));
+#if ATT_DMA_IN_MFMA
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // all but K(j+2): V(j+1) has landed
+#else
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // V(j+1) has landed
+#endif
+    ATT_STAMP8(5);
+    PP_BARRIER();
+    // ---------------- PV: O^T += V^T . P^T (four independent accumulator chains)
+    ATT_STAMP8(6);
+    lds_wait_frags(frag);
+    // first 32-key block: 8 MFMAs, one step of the second block's exponentials behind each
+    static_for<0, 8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, s_ = i >> 2, db = i & 3;
+      oacc[db] = mfma32<F16>(frag[s_ * 4 + db], pf[0][s_], oacc[db]);
+      exp_step(IntC<1>{}, ic);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    l_run += ps2[0] + ps2[1];
+    ps2 = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) oacc[db] = mfma32<F16>(frag[(2 + s_) * 4 + db], pf[1][s_], oacc[db]);
+#if ATT_DMA_IN_MFMA
+      if (s_ == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_v(j + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
+    }
+    asm volatile("" : "+v"(l_run));
+    ATT_STAMP8(7);
+    PP_BARRIER();
+  }
+  if (!grp) PP_BARRIER();   // waves 0-3 close the stagger (equal barrier counts)
+#undef PP_BARRIER
+
+#ifdef RTV_ATTN_TRACE
+  if (tr_on && lane < 32 && ntiles >= 24) tr_dst[lane] = tr_lds[lane];
+#endif
+  // ---------------- epilogue: O = O^T / l, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_row < p.Lq) {
+    uint16_t* op = ob + (size_t)q_row * p.o_rs + 4 * g;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x2 w;
+        w[0] = pack2<F16>(oacc[db][4 * i + 0] * inv, oacc[db][4 * i + 1] * inv);
+        w[1] = pack2<F16>(oacc[db][4 * i + 2] * inv, oacc[db][4 * i + 3] * inv);
+        *(u32x2*)(op + db * 32 + i * 8) = w;
+      }
+  }
+}
+
 }  // namespace rtv
 
 using namespace rtv;
@@ -361,11 +778,16 @@ extern "C" int rtv_attn_debug_trace(unsigned* buf) {
 }
 #endif
 
-static int g_attn_waves = 0;  // 0 = by grid size
+static int g_attn_waves = 0;     // 0 = by grid size
+static bool g_attn_lockstep = false;  // 256-row launches on the lockstep kernel only (A/B runs, tests)
+static bool g_attn_force_pp = false;  // ... on the four-phase kernel whatever the window length
 
 extern "C" int rtv_attn_set_waves(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8) return set_error(-1, "attn_set_waves: 0 (auto), 4 or 8");
-  g_attn_waves = waves;
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82)
+    return set_error(-1, "attn_set_waves: 0 (auto), 4, 8, 81 (8 waves, lockstep schedule) or 82 (8 waves, four-phase schedule)");
+  g_attn_lockstep = waves == 81;
+  g_attn_force_pp = waves == 82;
+  g_attn_waves = waves > 8 ? 8 : waves;
   return 0;
 }
 
@@ -441,6 +863,37 @@ extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, voi
   double kv_avg = Lkv;  // dense; block-causal work is smaller (reported as dense upper bound / 1)
   ProfScope prof(PROF_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Lq * kv_avg * ATT_D);
   const dim3 g(grid), t(waves * 64);
+  // Four-phase kernel: its DMA addresses K / V rows with non-negative 32-bit byte offsets from a buffer base, so the base is
+  // the lowest row of the window (the second range of a ring window lies BELOW the first one).
+  p.off0 = 0;
+  const int base_shift = (Lkv1 > 0 && seg1_row < 0) ? seg1_row : 0;
+  const int64_t top0 = (int64_t)p.n0 - base_shift, top1 = (int64_t)Lkv + p.delta - base_shift;
+  const int64_t rs_max = k_row_stride > v_row_stride ? k_row_stride : v_row_stride;
+  const bool offsets_fit = k_row_stride > 0 && v_row_stride > 0 &&
+                           ((top0 > top1 ? top0 : top1) + ATT_KT) * rs_max * 2 < 0x7fffffffLL;
+  // Short key windows (the 512-key cross-attention) stay on the lockstep kernel: the four-phase one stages two tiles before its
+  // first MFMA and pays four barriers per tile (measured 93 vs 84 us at 4680 x 512 x 40; +1..4 % from 4680 keys on).
+  if (waves == 8 && !g_attn_lockstep && offsets_fit && (Lkv >= 1024 || g_attn_force_pp)) {
+    p.k += (int64_t)base_shift * k_row_stride;
+    p.v += (int64_t)base_shift * v_row_stride;
+    p.off0 = -base_shift;
+    p.delta -= base_shift;
+#ifdef RTV_ATTN_TRACE
+    const int lds_pp = 2 * ATT_NB * ATT_TILE_BYTES + 256;   // + the stamp area of the lab build
+#else
+    const int lds_pp = 2 * ATT_NB * ATT_TILE_BYTES;
+#endif
+    static bool pp_attr[2] = {false, false};
+    const void* kp = f16 ? (const void*)attn_fwd_pp_kernel<true> : (const void*)attn_fwd_pp_kernel<false>;
+    if (!pp_attr[f16]) {
+      hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp);
+      if (e != hipSuccess) return set_error(e, "attn_fwd: hipFuncSetAttribute");
+      pp_attr[f16] = true;
+    }
+    if (f16) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), g, t, lds_pp, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), g, t, lds_pp, (hipStream_t)stream, p);
+    return check_launch("attn_fwd");
+  }
   if (waves == 4) {
     if (f16) hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), g, t, lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), g, t, lds, (hipStream_t)stream, p);

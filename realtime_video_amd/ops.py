@@ -59,7 +59,8 @@ def prof_read(cls):
 
 # --------------------------------------------------------------------------------------- attention
 def attn_set_waves(waves=0):
-    """Workgroup shape of attn_fwd: 8 (256 query rows), 4 (128 rows) or 0 = by grid size (rtv_attn_set_waves)."""
+    """Workgroup shape of attn_fwd: 8 (256 query rows), 4 (128 rows) or 0 = by grid size; 81 / 82 = 256 rows on the lockstep /
+    four-phase schedule regardless of the window length (rtv_attn_set_waves)."""
     _lib.call("rtv_attn_set_waves", int(waves))
 
 

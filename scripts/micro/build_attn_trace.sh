@@ -3,5 +3,5 @@
 set -e
 cd "$(dirname "$0")"
 C=../../realtime_video_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRTV_ATTN_TRACE -Wno-unused-value \
-  $C/attn_fwd.hip $C/runtime.hip $C/gemm.hip $C/gemm8.hip -o libattn_tr.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRTV_ATTN_TRACE $ATT_LAB_FLAGS -Wno-unused-value \
+  $C/attn_fwd.hip $C/runtime.hip $C/gemm.hip $C/gemm8.hip -o ${ATT_LAB_OUT:-libattn_tr.so}

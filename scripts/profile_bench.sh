@@ -17,6 +17,9 @@ SUM=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT $SUM
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r -- python $R/bench.py $ARGS > $OUT/trace.log 2>&1
+if [ "${PMC:-1}" = "0" ]; then          # PMC=0: kernel-time table only
+  cd $R; python scripts/traffic_summary.py $OUT $SUM; exit 0
+fi
 # PMC passes run on the bare kernels at the bench's shapes (rocprofv3 --pmc over the whole multi-thousand-launch
 # bench process segfaults inside the profiler on this image): the six projection GEMMs of one 14B DiT layer at
 # M = 4680 rows (default tile config = what the bench uses; 100 launches per shape and pass) and the self-attention call

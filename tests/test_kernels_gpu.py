@@ -704,3 +704,61 @@ def test_scheduler_step_refuses_what_it_does_not_cover(ops):
     # float32 latents keep the eager chain (still on the GPU)
     out = sch.add_noise(a.float(), a.float(), t)
     assert out.dtype == torch.float32
+
+
+# ----------------------------------------------------------------------------------------- attention: four-phase kernel
+def _both_schedules(ops, fn):
+    outs = []
+    try:
+        for w in (81, 82):
+            ops.attn_set_waves(w)
+            outs.append(fn())
+    finally:
+        ops.attn_set_waves(0)
+    return outs
+
+
+@pytest.mark.parametrize("B,Lq,Lkv,H,cb,dt", [
+    (1, 600, 1024, 2, 0, torch.bfloat16), (1, 333, 1000, 3, 96, torch.bfloat16), (2, 300, 333, 2, 0, torch.float16),
+    (1, 256, 64, 1, 0, torch.bfloat16), (1, 100, 70, 2, 0, torch.bfloat16), (1, 257, 129, 2, 0, torch.bfloat16),
+    (1, 1040, 1040, 2, 520, torch.bfloat16), (1, 512, 191, 8, 0, torch.bfloat16), (1, 1560, 3000, 8, 0, torch.bfloat16)])
+def test_attention_four_phase_kernel_equals_lockstep_and_reference(ops, B, Lq, Lkv, H, cb, dt):
+    """The four-phase kernel (LDS-DMA staging, fragments read a phase ahead) accumulates in the same order as the lockstep
+    one: outputs are bit-identical, on ragged windows, one-tile windows, the block-causal prefix and fp16 alike; both are
+    within the stated tolerance of the fp32 reference.  Keys grow along the sequence so that rescales fire late."""
+    q = _randn(B, Lq, H, 128, seed=1, dtype=dt)
+    k = (_randn(B, Lkv, H, 128, seed=2, dtype=torch.float32) * torch.linspace(0.3, 3.0, Lkv, device=DEV).view(1, Lkv, 1, 1)).to(dt)
+    v = _randn(B, Lkv, H, 128, seed=3, dtype=dt)
+    q_off = Lkv - Lq if cb and Lkv > Lq else 0
+    a, b = _both_schedules(ops, lambda: ops.attn_fwd(q, k, v, causal_block=cb, q_offset=q_off))
+    assert torch.equal(a, b)
+    lim = None
+    if cb:
+        lim = torch.clamp(((torch.arange(Lq, device=DEV) + q_off) // cb + 1) * cb, max=Lkv)
+    assert max_abs(b, _attn_ref(q, k, v, lim)) <= (4e-3 if dt == torch.float16 else 3e-2)
+
+
+@pytest.mark.parametrize("seg0,seg1", [((2000, 700), (100, 333)), ((100, 333), (2000, 700)), ((64, 64), (0, 64)),
+                                       ((1000, 1), (10, 130)), ((500, 1000), (0, 0)), ((2900, 100), (0, 1500))])
+def test_attention_four_phase_kernel_two_range_windows(ops, seg0, seg1):
+    """Ring windows: the second range below the first one (a wrapped ring - the DMA base moves to the lowest row), above it,
+    tile-straddling boundaries; equal to the lockstep kernel and to attention over the concatenated keys."""
+    kc, vc = _randn(1, 3000, 4, 128, seed=5), _randn(1, 3000, 4, 128, seed=6)
+    q = _randn(1, 520, 4, 128, seed=7)
+    a, b = _both_schedules(ops, lambda: ops.attn_fwd_win(q, kc, vc, seg0, seg1))
+    kk = torch.cat([kc[:, seg0[0]:seg0[0] + seg0[1]], kc[:, seg1[0]:seg1[0] + seg1[1]]], 1).contiguous()
+    vv = torch.cat([vc[:, seg0[0]:seg0[0] + seg0[1]], vc[:, seg1[0]:seg1[0] + seg1[1]]], 1).contiguous()
+    ref, ref_pp = _both_schedules(ops, lambda: ops.attn_fwd(q, kk, vv))
+    assert torch.equal(a, b) and torch.equal(b, ref) and torch.equal(ref, ref_pp)
+
+
+def test_attention_four_phase_kernel_strided_cache_views_full_size(ops):
+    """14B layer geometry: 4680 query rows, 40 heads, keys in place in a [rows, H, 128] cache whose row stride is the whole
+    model width, window of 9360 rows starting mid-cache; default dispatch (four-phase) == lockstep, bit for bit."""
+    H = 40
+    kc = _randn(1, 9360 + 700, H, 128, seed=2)
+    vc = _randn(1, 9360 + 700, H, 128, seed=3)
+    q = _randn(1, 4680, H, 128, seed=1)
+    k, v = kc[:, 333:333 + 9360], vc[:, 333:333 + 9360]
+    a, b = _both_schedules(ops, lambda: ops.attn_fwd(q, k, v))
+    assert torch.equal(a, b) and torch.equal(ops.attn_fwd(q, k, v), b)
