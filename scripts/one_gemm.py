@@ -10,6 +10,7 @@ from realtime_video_amd import ops  # noqa: E402
 cfg = int(sys.argv[1])
 m, n, k = (int(x) for x in sys.argv[2:5]) if len(sys.argv) > 4 else (4680, 13824, 5120)
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+ops.ensure_gemm_workspace(torch.device("cuda"))   # split-K tail units, as in the model
 a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
 w = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
 b = torch.randn(n, device="cuda").to(torch.bfloat16)

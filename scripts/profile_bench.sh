@@ -22,16 +22,14 @@ if [ "${PMC:-1}" = "0" ]; then          # PMC=0: kernel-time table only
 fi
 # PMC passes run on the bare kernels at the bench's shapes (rocprofv3 --pmc over the whole multi-thousand-launch
 # bench process segfaults inside the profiler on this image): the six projection GEMMs of one 14B DiT layer at
-# M = 4680 rows (default tile config = what the bench uses; 100 launches per shape and pass) and the self-attention call
+# M = 4680 rows (default tile config = what the bench uses; 100 launches per layer GEMM and pass) and the self-attention call
 # of a denoising step.
 i=0
 for shape in "15360 5120" "5120 5120" "13824 5120" "5120 13824"; do
   i=$((i+1))
-  reps=1; [ "$shape" = "5120 5120" ] && reps=3          # o-proj, cross-q, cross-o share a shape
-  for r in $(seq $reps); do
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch_g${i}_$r -o r -- python $R/scripts/one_gemm.py 0 4680 $shape 100 > $OUT/fetch_g$i.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write_g${i}_$r -o r -- python $R/scripts/one_gemm.py 0 4680 $shape 100 > $OUT/write_g$i.log 2>&1
-  done
+  n=100; [ "$shape" = "5120 5120" ] && n=300          # o-proj, cross-q, cross-o share a shape: weighted 3x
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch_g${i} -o r -- python $R/scripts/one_gemm.py 0 4680 $shape $n > $OUT/fetch_g$i.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write_g${i} -o r -- python $R/scripts/one_gemm.py 0 4680 $shape $n > $OUT/write_g$i.log 2>&1
 done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch_attn -o r -- python $R/scripts/one_attn.py 4680 9360 40 5 > $OUT/fetch_attn.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write_attn -o r -- python $R/scripts/one_attn.py 4680 9360 40 5 > $OUT/write_attn.log 2>&1

@@ -350,28 +350,31 @@ def test_conv3d_full_resolution_layer():
 def test_full_resolution_streaming_decode_matches_fp32_oracle():
     """The decoder at the benchmarked size against the ORACLE: latents 60 x 104 -> 480 x 832 pixels, a first call on fresh
     caches (2 latent frames -> 1 + 4 pixel frames) and a streamed second call on the returned caches (1 latent frame -> 4
-    frames), vs `vae_oracle.decoder_wrapper_forward` in fp32 on the host cores.  Tolerances of the golden test above: max-abs
-    within 2x the error of the same graph in eager fp16 (the reference's precision, run on this GPU) with a 2e-2 floor, hard
-    cap 5e-2, mean-abs <= 2e-3 on [-1, 1] pixels."""
-    import os
+    frames), vs `vae_oracle.decoder_wrapper_forward` in fp32.  The oracle graph is evaluated by torch on the GPU here (fp32
+    eager, MIOpen convolutions): on the host cores the same three latent frames cost 4-25 minutes depending on the box, and
+    the CPU evaluation of this oracle is what the small-size tests pin to the reference golden
+    (test_vae_oracle_vs_golden.py, test_streaming_decoder_matches_reference_golden).  Tolerances of the golden test above:
+    max-abs within 2x the error of the same graph in eager fp16 (the reference's precision) with a 2e-2 floor, hard cap
+    5e-2, mean-abs <= 2e-3 on [-1, 1] pixels."""
     from oracle import vae_oracle as vo
     from realtime_video_amd.vae_decoder import VAEDecoderWrapper
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
     w = vo.make_vae_weights(seed=0)
     g = torch.Generator().manual_seed(21)
     zs = [torch.randn(1, 2, 16, 60, 104, generator=g), torch.randn(1, 1, 16, 60, 104, generator=g)]
     dec = VAEDecoderWrapper(DEV)
     dec.load_state_dict(w)
+    w32 = {k: v.float().to(DEV) for k, v in w.items()}
     w16 = {k: v.half().to(DEV) for k, v in w.items()}
     cache, cache32, cache16 = [None] * 55, [None] * 55, [None] * 55
     for i, z in enumerate(zs):
         px, cache = dec(z.half().to(DEV), *cache)
         with torch.inference_mode():
-            ref, cache32 = vo.decoder_wrapper_forward(w, z.half().float(), cache32)
+            ref, cache32 = vo.decoder_wrapper_forward(w32, z.half().float().to(DEV), cache32)
             px16, cache16 = vo.decoder_wrapper_forward(w16, z.half().to(DEV), cache16)
+        assert ref.dtype == torch.float32
         assert px.shape == ref.shape == (1, 5 if i == 0 else 4, 3, 480, 832) and px.dtype == torch.float32
-        err, err16 = max_abs(px.cpu(), ref), max_abs(px16.float().cpu(), ref)
-        mean_err = float((px.cpu() - ref).abs().mean())
+        err, err16 = max_abs(px, ref), max_abs(px16.float(), ref)
+        mean_err = float((px - ref).abs().mean())
         assert err <= max(2 * err16, 2e-2) and err <= 5e-2, (i, err, err16)
         assert mean_err <= 2e-3, (i, mean_err)
         assert float(px.abs().max()) <= 1.0
@@ -379,7 +382,7 @@ def test_full_resolution_streaming_decode_matches_fp32_oracle():
         assert (c is None) == (c32 is None)
         if c is not None:
             assert tuple(c.shape) == tuple(c32.shape)
-            assert rel_l2(c[0, ::5, :, ::7, ::9].float().cpu(), c32[0, ::5, :, ::7, ::9]) <= 2e-2
+            assert rel_l2(c[0, ::5, :, ::7, ::9].float(), c32[0, ::5, :, ::7, ::9]) <= 2e-2
 
 
 def test_full_size_decode_row_sharded_equals_unsharded():
