@@ -592,9 +592,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
 #if !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA
     stage_k(j + 2);
 #endif
-#ifdef ATT_LAB_T5
-    stage_v(j + 2);
-#endif
 #pragma unroll
     for (int dc = 0; dc < 8; ++dc)
 #pragma unroll
@@ -635,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
     // ~256 cycles for the group): they are issued in small groups BETWEEN the pieces of the softmax, so the VALU work runs
     // while the LDS serves them instead of behind a full read queue.
     ATT_STAMP8(4);
-#if !defined(ATT_LAB_T5) && !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA   // (T5: V DMA issued in LK; T6: no DMA in the loop)
+#if !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA   // (lab build T6: no DMA in the loop)
     stage_v(j + 2);
 #endif
     uint32_t va[4];

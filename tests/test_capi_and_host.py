@@ -389,3 +389,54 @@ def test_cache_window_matches_the_real_reference_model_on_random_sequences():
             assert bool(written[:hi].all()) and not bool(written[hi:].any()), (trial, call)     # rows [0, local_end) are live
             prev = (cur, frames)
             cur += frames * fs
+
+
+# ------------------------------------------------------------------------------------------------ VAE cache arenas
+def test_vae_cache_arena_registry_finds_rebuilds_and_refuses():
+    """vae_decoder.CacheArenas (host logic, no kernels): a cache list is recognised by the address of its first slot, a list
+    of cloned slots is copied into a new arena (contents preserved, list updated in place), a list of another frame size
+    or with a mismatching slot is refused, and only the last few arenas are kept alive by the registry."""
+    from realtime_video_amd.vae_decoder import CacheArenas
+
+    def make_views(arena, base, reg, size):
+        views = [arena[base + 16 * i: base + 16 * (i + 1)].view(torch.float16) for i in range(3)] + [None]
+        reg.register(views, arena, base, size)
+        return views
+
+    reg = CacheArenas()
+    arena = torch.zeros(64 + 256, dtype=torch.uint8)
+    views = make_views(arena, 4, reg, (8, 12))
+    for i, v in enumerate(views[:3]):
+        v.fill_(i + 1)
+    got_arena, got_base = reg.lookup(list(views), (8, 12), None, None)
+    assert got_arena is arena and got_base == 4
+    with pytest.raises(ValueError):
+        reg.lookup(list(views), (8, 20), None, None)
+    # cloned slots: a new arena, contents carried over, the caller's list now holds views of it
+    made = []
+
+    def new_arena():
+        made.append(torch.zeros(64 + 256, dtype=torch.uint8))
+        return made[-1]
+
+    snap = [None if v is None else v.clone() for v in views]
+    a2, b2 = reg.lookup(snap, (8, 12), new_arena, lambda a, b: make_views(a, b, reg, (8, 12)))
+    assert a2 is made[0] and a2 is not arena and b2 == (-a2.data_ptr()) % 256
+    assert all(torch.equal(s, v) for s, v in zip(snap[:3], views[:3])) and snap[3] is None
+    assert snap[0].data_ptr() == a2.data_ptr() + b2          # a view of the new arena
+    assert reg.lookup(snap, (8, 12), None, None)[0] is a2     # ... which is registered
+    # a slot that should be a tensor is None (or has another shape): refused
+    bad = [v.clone() for v in views[:3]] + [None]
+    bad[1] = None
+    with pytest.raises(ValueError):
+        reg.lookup(bad, (8, 12), new_arena, lambda a, b: make_views(a, b, reg, (8, 12)))
+    bad = [v.clone() for v in views[:3]] + [None]
+    bad[2] = torch.zeros(5, dtype=torch.float16)
+    with pytest.raises(ValueError):
+        reg.lookup(bad, (8, 12), new_arena, lambda a, b: make_views(a, b, reg, (8, 12)))
+    # eviction: only KEEP arenas stay registered
+    keep = []
+    for _ in range(CacheArenas.KEEP + 2):
+        a = torch.zeros(64 + 256, dtype=torch.uint8)
+        keep.append(make_views(a, 0, reg, (8, 12)))
+    assert len(reg._by_ptr) == CacheArenas.KEEP
