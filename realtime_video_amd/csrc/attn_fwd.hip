@@ -377,9 +377,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
 //     phase 4j-1; a tile's DMA is complete (issuer's vmcnt + the phase barrier) >= 3 phases before its first read.
 // Registers: Q^T 32 + O^T 64 + S^T 32 + P^T 16 + fragments 64 = 208 of the 256 a wave has at two waves per SIMD.
 constexpr int ATT_NB = 3;   // ring slots per operand
-#ifndef ATT_DMA_IN_MFMA
-#define ATT_DMA_IN_MFMA 0   // 1: K / V DMA issued inside the QK / PV phases instead of the load phases (measured: -3 %)
-#endif
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -395,6 +392,12 @@ template <int OFF>
 __device__ __forceinline__ u32x2 lds_tr_read_at(uint32_t lds_addr) {
   u32x2 r;
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128_at(uint32_t lds_addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
   return r;
 }
 // s_waitcnt lgkmcnt(0) that the fragment registers depend on (so no consumer can be scheduled above it)
@@ -482,6 +485,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
   const int st_row = wave * 8 + (lane >> 4);   // tile row of piece 0 (piece 1: + 4)
   const int st_cp = lane & 15;
   const int k_rs = (int)p.k_rs, v_rs = (int)p.v_rs;
+  // window constants pinned in SGPRs: left to itself the compiler turns `in0 ? p.off0 : p.delta` into an s_load from the kernel
+  // argument segment at a selected address plus `s_waitcnt lgkmcnt(0)` in front of every DMA issue (a scalar-memory round trip
+  // and a drain of the LDS reads in flight, twice per tile)
+  const int w_off0 = __builtin_amdgcn_readfirstlane(p.off0), w_delta = __builtin_amdgcn_readfirstlane(p.delta);
+  const int w_n0 = __builtin_amdgcn_readfirstlane(p.n0), w_lkv = __builtin_amdgcn_readfirstlane(p.Lkv);
   int k_ch[2], v_ch[2];
   uint32_t k_fast[2], v_fast[2];
 #pragma unroll
@@ -496,17 +504,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
                    const int (&ch)[2]) {
     const int row0 = j * ATT_KT;
     char* const dst = ring + (j % ATT_NB) * ATT_TILE_BYTES + wave * (8 * 256);
-    const bool in0 = row0 + ATT_KT <= p.n0;
-    if (in0 || (row0 >= p.n0 && row0 + ATT_KT <= p.Lkv)) {
-      const uint32_t so = (uint32_t)((row0 + (in0 ? p.off0 : p.delta)) * rs) * 2u;
+    const bool in0 = row0 + ATT_KT <= w_n0;
+    if (in0 || (row0 >= w_n0 && row0 + ATT_KT <= w_lkv)) {
+      const uint32_t so = (uint32_t)((row0 + (in0 ? w_off0 : w_delta)) * rs) * 2u;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (RTV_LDS void*)(dst + i * 1024), 16, fast[i], so, 0, 0);
     } else {   // (also every tile past the end: clamped rows into a slot nobody reads - the wait counts stay uniform)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        int kv = min(row0 + st_row + 4 * i, p.Lkv - 1);
-        kv += kv >= p.n0 ? p.delta : p.off0;
+        int kv = min(row0 + st_row + 4 * i, w_lkv - 1);
+        kv += kv >= w_n0 ? w_delta : w_off0;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (RTV_LDS void*)(dst + i * 1024), 16,
                                                  (uint32_t)(kv * rs + ch[i]) * 2u, 0, 0, 0);
       }
@@ -528,9 +536,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
   }
 
   // ---- per-lane LDS read addresses (slot 0); K operand (A): row = kbk*32 + l31, chunk = (dc*2 + g) ^ (row & 15)
-  const char* k_rd[8];
+  uint32_t k_rd32[8];   // 32-bit LDS addresses: every fragment read of this kernel is inline asm (see lds_tr_read_at)
 #pragma unroll
-  for (int dc = 0; dc < 8; ++dc) k_rd[dc] = sK + l31 * 256 + (((dc * 2 + g) ^ (l31 & 15)) << 4);
+  for (int dc = 0; dc < 8; ++dc)
+    k_rd32[dc] = (uint32_t)(uintptr_t)(RTV_LDS const char*)(sK + l31 * 256 + (((dc * 2 + g) ^ (l31 & 15)) << 4));
   // V^T operand (A) via transpose read: 16-lane group gathers a [4 keys][16 dims] block
   const int i16 = lane & 15, h16 = (lane >> 4) & 1;
   uint32_t v_rd32[4];   // 32-bit LDS addresses (the transpose reads are inline asm)
@@ -589,56 +598,26 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
     const int slot_off = (j % ATT_NB) * ATT_TILE_BYTES;
     // ---------------- LK
     ATT_STAMP8(0);
-#if !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA
+#ifndef ATT_LAB_T6
     stage_k(j + 2);
 #endif
-#pragma unroll
-    for (int dc = 0; dc < 8; ++dc)
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) frag[dc * 2 + kbk] = *(const u32x4*)(k_rd[dc] + slot_off + kbk * 32 * 256);
-#if ATT_DMA_IN_MFMA
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // everything but the youngest issue point (V(j+1)): K(j+1) has landed
-#else
+    static_for<0, 16>([&](auto ic) {   // fragment n = [dc = n >> 1][kbk = n & 1]
+      constexpr int n = decltype(ic)::value;
+      frag[n] = lds_read128_at<(n & 1) * 32 * 256>(k_rd32[n >> 1] + (uint32_t)slot_off);
+    });
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything but the two youngest issue points: K(j+1) has landed
-#endif
     ATT_STAMP8(1);
     PP_BARRIER();
-    // ---------------- QK: S^T = K . Q^T (two independent accumulator chains)
+    // ---------------- QK: S^T = K . Q^T (two independent accumulator chains).  MFMA n consumes fragment register n; the V^T
+    // fragment n of the same tile is read into that register right behind it (a transpose read costs an issue slot in the
+    // shadow of the matrix pipe here, and ~9 cycles of LDS queueing when all four waves of a group issue their 32 at once in
+    // the LV phase, where the softmax then waits behind them).
     ATT_STAMP8(2);
-#pragma unroll
-    for (int dc = 0; dc < 8; ++dc)
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
-        if (dc == 0) {
-          f32x16 z;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) z[r] = 0.f;
-          sacc[kbk] = mfma32<F16>(frag[kbk], qf[0], z);
-        } else {
-          sacc[kbk] = mfma32<F16>(frag[dc * 2 + kbk], qf[dc], sacc[kbk]);
-        }
-#if ATT_DMA_IN_MFMA
-        if (dc == 3 && kbk == 1) {   // the K DMA of tile j+2 in the shadow of the matrix pipe
-          __builtin_amdgcn_sched_barrier(0);
-          stage_k(j + 2);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
-      }
-    ATT_STAMP8(3);
-    PP_BARRIER();
-    // ---------------- LV: V^T fragments, V DMA, mask + online softmax
-    // The 32 transpose reads are LDS-throughput bound when the four waves of a group issue them together (2 LDS cycles each,
-    // ~256 cycles for the group): they are issued in small groups BETWEEN the pieces of the softmax, so the VALU work runs
-    // while the LDS serves them instead of behind a full read queue.
-    ATT_STAMP8(4);
-#if !defined(ATT_LAB_T6) && !ATT_DMA_IN_MFMA   // (lab build T6: no DMA in the loop)
-    stage_v(j + 2);
-#endif
+    lds_wait_frags(frag);
     uint32_t va[4];
 #pragma unroll
     for (int db = 0; db < 4; ++db) va[db] = v_rd32[db] + (uint32_t)slot_off;
-    auto rd_v = [&](auto ic) {   // fragment idx = (kbk*2 + s)*4 + db
+    auto rd_v = [&](auto ic) {   // V^T fragment idx = (kbk*2 + s)*4 + db
 #ifndef ATT_LAB_T4   // (T4, timing experiment: no V reads - PV runs on the K fragments)
       constexpr int idx = decltype(ic)::value;
       constexpr int off = ((idx >> 3) * 32 + ((idx >> 2) & 1) * 16) * 256;
@@ -647,10 +626,30 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
       frag[idx] = u32x4{lo[0], lo[1], hi[0], hi[1]};
 #endif
     };
-#define LV_FENCE() __builtin_amdgcn_sched_barrier(0)
-    rd_v(IntC<0>{});
-    rd_v(IntC<1>{});
-    LV_FENCE();
+    static_for<0, 8>([&](auto ic) {
+      constexpr int dc = decltype(ic)::value;
+      if constexpr (dc == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        sacc[0] = mfma32<F16>(frag[0], qf[0], z);
+        sacc[1] = mfma32<F16>(frag[1], qf[0], z);
+      } else {
+        sacc[0] = mfma32<F16>(frag[2 * dc], qf[dc], sacc[0]);
+        sacc[1] = mfma32<F16>(frag[2 * dc + 1], qf[dc], sacc[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      rd_v(IntC<2 * dc>{});
+      rd_v(IntC<2 * dc + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    ATT_STAMP8(3);
+    PP_BARRIER();
+    // ---------------- LV: V DMA, mask + online softmax (first 32-key block of the exponentials)
+    ATT_STAMP8(4);
+#ifndef ATT_LAB_T6
+    stage_v(j + 2);
+#endif
     if ((j + 1) * ATT_KT > wave_min_lim) {   // mask: only on tiles that cross a limit of this wave
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
@@ -664,16 +663,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
       float mx = sacc[0][0];
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
-      LV_FENCE();
-      rd_v(IntC<2>{});
-      rd_v(IntC<3>{});
-      LV_FENCE();
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
-      LV_FENCE();
-      rd_v(IntC<4>{});
-      rd_v(IntC<5>{});
-      LV_FENCE();
       mx = xor32_max(mx);
       const float m_cand = fmaxf(m_run, mx * c);
       const bool need = m_cand - m_run > RESCALE_SLACK;
@@ -689,29 +680,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
       }
-      LV_FENCE();
-      rd_v(IntC<6>{});
-      rd_v(IntC<7>{});
-      LV_FENCE();
       // exponentials of the first 32-key block here; those of the second block run inside the PV phase, between the
       // MFMAs of the first block (the wave's own issue slots while the matrix pipe works)
-      static_for<0, 8>([&](auto ic) {
-        constexpr int t = decltype(ic)::value;
-        exp_step(IntC<0>{}, ic);
-        LV_FENCE();
-        rd_v(IntC<8 + t>{});
-        LV_FENCE();
-      });
+      static_for<0, 8>([&](auto ic) { exp_step(IntC<0>{}, ic); });
     }
-#undef LV_FENCE
     // the first half of P^T is complete HERE: without this the compiler sinks exponentials / packs below the barrier, into
     // the matrix phase (sched_barrier does not stop its code sinking)
     asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(ps2));
-#if ATT_DMA_IN_MFMA
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // all but K(j+2): V(j+1) has landed
-#else
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // V(j+1) has landed
-#endif
     ATT_STAMP8(5);
     PP_BARRIER();
     // ---------------- PV: O^T += V^T . P^T (four independent accumulator chains)
@@ -730,13 +706,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
     for (int s_ = 0; s_ < 2; ++s_) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) oacc[db] = mfma32<F16>(frag[(2 + s_) * 4 + db], pf[1][s_], oacc[db]);
-#if ATT_DMA_IN_MFMA
-      if (s_ == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        stage_v(j + 2);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#endif
     }
     asm volatile("" : "+v"(l_run));
     ATT_STAMP8(7);
