@@ -290,10 +290,13 @@ def main():
     for _ in range(args.steps):
         out = sess.generate_block()
         frames += 12
+    host_issue_s = time.perf_counter() - t0   # host side of the timed blocks (launch issue; the GPU may still be running)
     if tickets:
         downloader.fetch(tickets.pop())
     barrier()
     elapsed = time.perf_counter() - t0
+    print(f"[bench] rank {rank}: host issue time {1e3 * host_issue_s / args.steps:.1f} ms per block of {1e3 * elapsed / args.steps:.1f} ms",
+          file=sys.stderr)
     ops.prof_enable(False)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
