@@ -60,7 +60,10 @@ def cpu_baseline(model_cfg, with_vae=True):
     (4 denoise + 0.88 recompute-equivalent) x L layer-forwards, plus ONE latent frame of the streaming VAE decode at
     480 x 832 on warm caches (fp32; 4 of the block's 12 pixel frames) extrapolated x3."""
     from oracle import wan_oracle as wo
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))   # the cores this process may use (a cgroup / cpuset can be narrower than the host)
+    except AttributeError:
+        cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     d, ffn, H = model_cfg["dim"], model_cfg["ffn_dim"], model_cfg["num_heads"]
     g = torch.Generator().manual_seed(0)
