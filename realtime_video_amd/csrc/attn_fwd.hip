@@ -366,15 +366,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
 //     `s_waitcnt vmcnt(4)` per issue point a whole tile before the data is read - no staging registers, no ds_write;
 //   * a tile is four phases per wave, separated by s_barrier:
 //         LK  read the 16 K fragments of the tile into registers (16 ds_read_b128), issue the K DMA of tile j+2
-//         QK  16 MFMAs on register operands                                  S^T = K . Q^T
-//         LV  read the 16 V^T fragments (32 transpose reads) into the SAME registers, issue the V DMA of tile j+2,
-//             mask + online softmax of S^T -> P^T (VALU, beside the partner's MFMAs)
-//         PV  16 MFMAs on register operands                                  O^T += V^T . P^T
+//         QK  16 MFMAs on register operands, S^T = K . Q^T; behind MFMA n the V^T fragment n of the tile is read (2 transpose
+//             reads) into the register MFMA n has just consumed - K and V^T fragments share one 64-register block, and the
+//             reads cost issue slots in the shadow of the matrix pipe instead of ~280 cycles in front of the softmax
+//         LV  issue the V DMA of tile j+2; mask, row maximum, lazy rescale, first half of the exponentials -> P^T (VALU beside
+//             the partner's MFMAs)
+//         PV  16 MFMAs on register operands, O^T += V^T . P^T, the second half of the exponentials between the first eight
 //     waves 4-7 run ONE phase behind waves 0-3, so in every phase one wave of each SIMD is in a matrix phase and its
 //     partner in a load/VALU phase:
 //         phase 4j: g0 LK(j)  g1 PV(j-1) | 4j+1: g0 QK(j)  g1 LK(j) | 4j+2: g0 LV(j)  g1 QK(j) | 4j+3: g0 PV(j)  g1 LV(j)
-//   * ring hazards: K(j+2) lands in the slot of K(j-1), last read in phase 4j-3; V(j+2) in the slot of V(j-1), last read in
-//     phase 4j-1; a tile's DMA is complete (issuer's vmcnt + the phase barrier) >= 3 phases before its first read.
+//   * every fragment read is inline asm: the compiler's wait-count pass puts vmcnt(0) in front of an LDS read it cannot
+//     disambiguate from a pending LDS DMA, and its lgkmcnt bookkeeping of the K reads would wait on the younger V^T reads;
+//     the consumers wait with one explicit lgkmcnt(0) the fragment registers depend on (lds_wait_frags)
+//   * ring hazards: K(j+2) lands in the slot of K(j-1), last read in phase 4j-3; V(j+2) (issued in phase 4j+2 or later) in the
+//     slot of V(j-1), last read in phase 4j-2; a tile's DMA is complete (issuer's vmcnt + the phase barrier) >= 2 phases
+//     before its first read.
 // Registers: Q^T 32 + O^T 64 + S^T 32 + P^T 16 + fragments 64 = 208 of the 256 a wave has at two waves per SIMD.
 constexpr int ATT_NB = 3;   // ring slots per operand
 
