@@ -519,6 +519,54 @@ def golden_t5():
     print("t5_encoder.pt", tuple(ctx.shape), float(ctx.abs().mean()))
 
 
+def golden_full_width():
+    """BASELINE config 3's width on the REFERENCE ITSELF: the upstream CausalWanModel with dim 5120 / 40 heads / ffn 13824, ONE
+    layer, bf16 on the host cores (SDPA fallback), M = 4680 query tokens at cache offset 4680 over a 9360-row window whose
+    first half holds earlier K/V (seeded) - flow, x0 and sampled cache rows.  Inputs and weights are regenerated from the
+    seeds by the test (tests/test_dit_gpu.py::test_full_width_14b_layer_matches_reference_golden); the file also records how
+    long the reference forward and the oracle port took on this container's cores (the bench's cpu_baseline is the port:
+    the Python reference cannot travel to the GPU box)."""
+    import time
+    ref = ref_shim.load()
+    cfg = dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, freq_dim=256, text_len=512, eps=1e-6,
+               num_frame_per_block=3)
+    w = wo.make_weights(cfg, seed=5, text_dim=256)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
+    ctx = torch.randn(40, 256, generator=g).to(torch.bfloat16)
+    t = torch.tensor([[713.0, 713.0, 713.0]])
+    old_k = torch.randn(1, 4680, 40, 128, generator=g).to(torch.bfloat16)
+    old_v = torch.randn(1, 4680, 40, 128, generator=g).to(torch.bfloat16)
+
+    def prefilled():
+        kv, ca = fresh_caches(cfg, 9360)
+        kv[0]["k"][:, :4680], kv[0]["v"][:, :4680] = old_k, old_v
+        kv[0]["global_end_index"] = kv[0]["local_end_index"] = 4680
+        return kv, ca
+
+    model = ref_shim.build_reference_model(ref, cfg, w, 256)
+    wr = ref_shim.build_reference_wrapper(ref, model)
+    out = {"cores": len(os.sched_getaffinity(0)), "threads": torch.get_num_threads()}
+    with torch.inference_mode():
+        for rep in range(2):                      # second (warm) run timed, like bench.py's cpu_baseline
+            kv, ca = prefilled()
+            t0 = time.perf_counter()
+            flow, x0 = wr(lat, {"prompt_embeds": [ctx]}, t, kv, ca, current_start=4680)
+            out["reference_forward_s"] = time.perf_counter() - t0
+        for rep in range(2):
+            kvp, cap = prefilled()
+            t0 = time.perf_counter()
+            pflow, _ = wo.wrapper_forward(w, cfg, wo.FlowMatchScheduler(), lat, [ctx], t, kvp, cap, 4680)
+            out["port_forward_s"] = time.perf_counter() - t0
+    out.update(flow=flow.clone(), x0=x0.clone(), k_new=kv[0]["k"][0, 4680::97].clone(), v_new=kv[0]["v"][0, 4680::97].clone(),
+               k_old_checksum=float(kv[0]["k"][0, :4680].double().abs().sum()),
+               local_end_index=int(kv[0]["local_end_index"]), global_end_index=int(kv[0]["global_end_index"]),
+               port_vs_reference_rel_l2=float((pflow.double() - flow.double()).norm() / flow.double().norm()))
+    torch.save(out, os.path.join(OUT, "dit_full_width_layer.pt"))
+    print("dit_full_width_layer.pt done: reference %.1f s, port %.1f s on %d threads, port vs reference rel-L2 %.2e" % (
+        out["reference_forward_s"], out["port_forward_s"], out["threads"], out["port_vs_reference_rel_l2"]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -538,6 +586,8 @@ if __name__ == "__main__":
         golden_wan_vae_wrapper(ref)
     if "t5" in which:
         golden_t5()
+    if "full_width" in which:   # not in the default list: minutes of host time (one 14B-width layer on the reference)
+        golden_full_width()
     if "session" in which:      # from here on load_release_server() has patched torch.cuda for the rest of the process
         golden_session()
     if "webcam" in which:

@@ -27,9 +27,10 @@ def sinusoidal_embedding_1d(dim, position):
     """wan/modules/model.py:15-24 (float64; device-agnostic)."""
     assert dim % 2 == 0
     half = dim // 2
-    position = position.type(torch.float64)
+    dev = position.device                       # table arithmetic always on the host (same bits wherever the graph runs)
+    position = position.cpu().type(torch.float64)
     sinusoid = torch.outer(position, torch.pow(10000, -torch.arange(half, dtype=torch.float64).div(half)))
-    return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
+    return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1).to(dev)
 
 
 def rope_params(max_seq_len, dim, theta=10000):
@@ -51,6 +52,7 @@ def rope_apply(x, grid, freqs, start_frame=0):
     """causal_rope_apply (causal_model.py:143-171); start_frame=0 gives rope_apply (model.py:39-66).
     x: [B, S, H, hd]; grid = (F, h, w); computed in float64, cast back with .type_as(x)."""
     n, c = x.size(2), x.size(3) // 2
+    freqs = freqs.to(x.device)
     parts = freqs.split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
     f, h, w = grid
     seq_len = f * h * w
@@ -99,8 +101,8 @@ def attention_math(q, k, v, kv_limit=None):
     qf, kf, vf = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
     s = qf @ kf.transpose(-1, -2) / math.sqrt(q.shape[-1])
     if kv_limit is not None:
-        kv_idx = torch.arange(k.shape[1]).view(1, 1, 1, -1)
-        s = s.masked_fill(kv_idx >= kv_limit.view(1, 1, -1, 1), float("-inf"))
+        kv_idx = torch.arange(k.shape[1], device=s.device).view(1, 1, 1, -1)
+        s = s.masked_fill(kv_idx >= kv_limit.to(s.device).view(1, 1, -1, 1), float("-inf"))
     return (torch.softmax(s, dim=-1) @ vf).transpose(1, 2).contiguous()
 
 
@@ -122,10 +124,10 @@ def attention_block_causal(q, k, v, block_len):
 # ------------------------------------------------------------------------------------------------
 # KV cache manager (pipeline/causal_inference.py:279-339)
 # ------------------------------------------------------------------------------------------------
-def initialize_kv_cache(num_layers, batch_size, kv_cache_size, num_heads, head_dim, dtype):
+def initialize_kv_cache(num_layers, batch_size, kv_cache_size, num_heads, head_dim, dtype, device="cpu"):
     """causal_inference.py:279-314 (fresh allocation branch)."""
-    return [{"k": torch.zeros(batch_size, kv_cache_size, num_heads, head_dim, dtype=dtype),
-             "v": torch.zeros(batch_size, kv_cache_size, num_heads, head_dim, dtype=dtype),
+    return [{"k": torch.zeros(batch_size, kv_cache_size, num_heads, head_dim, dtype=dtype, device=device),
+             "v": torch.zeros(batch_size, kv_cache_size, num_heads, head_dim, dtype=dtype, device=device),
              "global_end_index": 0, "local_end_index": 0} for _ in range(num_layers)]
 
 
@@ -138,10 +140,10 @@ def reset_kv_cache(kv_cache):
         c["local_end_index"] = 0
 
 
-def initialize_crossattn_cache(num_layers, batch_size, num_heads, head_dim, dtype, text_len=512):
+def initialize_crossattn_cache(num_layers, batch_size, num_heads, head_dim, dtype, text_len=512, device="cpu"):
     """causal_inference.py:316-339."""
-    return [{"k": torch.zeros(batch_size, text_len, num_heads, head_dim, dtype=dtype),
-             "v": torch.zeros(batch_size, text_len, num_heads, head_dim, dtype=dtype),
+    return [{"k": torch.zeros(batch_size, text_len, num_heads, head_dim, dtype=dtype, device=device),
+             "v": torch.zeros(batch_size, text_len, num_heads, head_dim, dtype=dtype, device=device),
              "is_init": False} for _ in range(num_layers)]
 
 
@@ -160,7 +162,7 @@ _FP8_MAX = 448.0
 def _fp8_scale(t):
     """Per-tensor scale max|t| / 448 as torchao's choose-scale evaluates it on the GPU (`amax / 448.0` with a Python scalar
     = multiplication by the fp32 reciprocal), clamped away from zero."""
-    inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(_FP8_MAX, dtype=torch.float32)
+    inv = torch.tensor(1.0, dtype=torch.float32, device="cpu") / torch.tensor(_FP8_MAX, dtype=torch.float32, device="cpu")
     return t.detach().float().abs().max().clamp(min=1e-12) * inv.to(t.device)
 
 
@@ -374,16 +376,18 @@ class FlowMatchScheduler:
     def add_noise(self, original_samples, noise, timestep):
         if timestep.ndim == 2:
             timestep = timestep.flatten(0, 1)
-        timestep_id = torch.argmin((self.timesteps.unsqueeze(0) - timestep.unsqueeze(1)).abs(), dim=1)
-        sigma = self.sigmas[timestep_id].reshape(-1, 1, 1, 1)
+        dev = noise.device                          # tables live on the host; the arithmetic runs where the samples are
+        timestep_id = torch.argmin((self.timesteps.to(dev).unsqueeze(0) - timestep.to(dev).unsqueeze(1)).abs(), dim=1)
+        sigma = self.sigmas.to(dev)[timestep_id].reshape(-1, 1, 1, 1)
         return ((1 - sigma) * original_samples + sigma * noise).type_as(noise)
 
 
 def convert_flow_pred_to_x0(scheduler, flow_pred, xt, timestep):
     """WanDiffusionWrapper._convert_flow_pred_to_x0, utils/wan_wrapper.py:181-205 (float64)."""
     original_dtype = flow_pred.dtype
-    flow_pred, xt, sigmas, timesteps = (a.double() for a in (flow_pred, xt, scheduler.sigmas, scheduler.timesteps))
-    timestep_id = torch.argmin((timesteps.unsqueeze(0) - timestep.unsqueeze(1)).abs(), dim=1)
+    dev = flow_pred.device
+    flow_pred, xt, sigmas, timesteps = (a.to(dev).double() for a in (flow_pred, xt, scheduler.sigmas, scheduler.timesteps))
+    timestep_id = torch.argmin((timesteps.unsqueeze(0) - timestep.to(dev).unsqueeze(1)).abs(), dim=1)
     sigma_t = sigmas[timestep_id].reshape(-1, 1, 1, 1)
     return (xt - sigma_t * flow_pred).to(original_dtype)
 
@@ -437,9 +441,10 @@ class SessionOracle:
         self.denoising_step_list = get_denoising_schedule(zp, strength, steps=num_steps)
         n_heads, hd = cfg["num_heads"], cfg["dim"] // cfg["num_heads"]
         kv_size = (self.c + self.nfpb) * FRAME_SEQLEN   # init_models, release_server.py:543-549
-        self.kv_cache = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype)
+        self.dev = noise.device                         # the graph runs where its inputs live (host, or torch eager on a GPU)
+        self.kv_cache = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype, self.dev)
         self.crossattn_cache = initialize_crossattn_cache(cfg["num_layers"], 1, n_heads, hd, noise.dtype,
-                                                          cfg.get("text_len", 512))
+                                                          cfg.get("text_len", 512), self.dev)
         self.rnd = torch.Generator().manual_seed(seed)
         self.first_frame_fn = first_frame_fn        # callable(block_idx) -> latent [1,1,16,h,w] (VAE re-encode)
 
@@ -465,7 +470,7 @@ class SessionOracle:
         start = min(self.current_start_frame, self.c)
         ctx = self.clean_context_frames()
         reset_kv_cache(self.kv_cache)
-        t0 = torch.zeros([1, ctx.shape[1]], dtype=torch.int64)
+        t0 = torch.zeros([1, ctx.shape[1]], dtype=torch.int64, device=self.dev)
         wrapper_forward(self.w, self.cfg, self.scheduler, ctx, self.prompt_embeds, t0, self.kv_cache,
                         self.crossattn_cache, start * FRAME_SEQLEN, recompute=True, attn_fn=self.attn_fn)
         return start
@@ -492,14 +497,14 @@ class SessionOracle:
                 c["is_init"] = False
             self.prompt_embeds = [self.interpolated_prompt_embeds.pop(0)[0]]
         for index, current_timestep in enumerate(steps):
-            timestep = torch.ones([1, self.nfpb], dtype=torch.int64) * current_timestep  # -> float32 (trap 4)
+            timestep = (torch.ones([1, self.nfpb], dtype=torch.int64) * current_timestep).to(self.dev)  # -> float32 (trap 4)
             _, denoised = wrapper_forward(self.w, self.cfg, self.scheduler, noisy, self.prompt_embeds, timestep,
                                           self.kv_cache, self.crossattn_cache, start * FRAME_SEQLEN,
                                           attn_fn=self.attn_fn)
             if index < len(steps) - 1:
                 nxt = steps[index + 1]
                 eps_noise = torch.randn(*denoised.flatten(0, 1).shape, generator=self.rnd, dtype=torch.bfloat16) \
-                    .to(denoised.dtype)
+                    .to(denoised)
                 noisy = self.scheduler.add_noise(denoised.flatten(0, 1), eps_noise,
                                                  nxt * torch.ones([self.nfpb], dtype=torch.long)) \
                     .unflatten(0, denoised.shape[:2])
@@ -548,7 +553,7 @@ class SessionOracle:
         s0 = self.denoising_step_list[0] / 1000
         lat, _ = self.encode_video_latent(encoder, [None] * 55, frames, max_frames=None)
         lat = lat[None].to(self.noise.dtype).movedim(1, 2)
-        eps = torch.randn(lat.shape, generator=self.rnd, dtype=self.noise.dtype)
+        eps = torch.randn(lat.shape, generator=self.rnd, dtype=self.noise.dtype).to(lat.device)
         self.noise = (lat * (1.0 - s0) + eps * s0).contiguous()
         self.num_blocks = min(lat.shape[1] // self.nfpb - 1, self.num_blocks)
 

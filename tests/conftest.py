@@ -15,7 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order on the GPU box: kernel-level parity first, then the VAE, the text encoder, the model / session level and
+# the two-process runs last - a slow box must never hide the kernel evidence behind end-to-end tests (GPUTEST_r02).
+_FILE_ORDER = ["test_kernels_gpu.py", "test_vae_gpu.py", "test_text_encoder_gpu.py", "test_dit_gpu.py",
+               "test_context_parallel_gpu.py"]
+PER_TEST_TIMEOUT_S = 180
+
+
 def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return _FILE_ORDER.index(name) if name in _FILE_ORDER else -1     # CPU files keep their place in front
+    items.sort(key=rank)                                                   # stable: order inside a file is kept
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(PER_TEST_TIMEOUT_S))
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")
@@ -37,9 +52,9 @@ def golden():
 
 
 def rel_l2(a, b):
-    a, b = a.double(), b.double()
+    a, b = a.double(), b.double().to(a.device)
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
 def max_abs(a, b):
-    return float((a.double() - b.double()).abs().max())
+    return float((a.double() - b.double().to(a.device)).abs().max())

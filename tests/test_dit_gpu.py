@@ -1,6 +1,6 @@
 """Model-level parity on the MI355X: the native DiT forward (rtv_dit_forward through the
 CausalWanModel / WanDiffusionWrapper / CausalInferencePipeline / GenerationSession mirrors) against
-golden vectors minted from the upstream reference and against the CPU oracle.
+golden vectors minted from the upstream reference and against the oracle graph (evaluated on the device, see _on_dev).
 
 Stated tolerance: gold = the same graph in fp32 on CPU; accept
 max_abs_err(ours, gold) <= 2 x max_abs_err(reference_bf16, gold) (+ small absolute floor) and
@@ -12,6 +12,14 @@ from conftest import max_abs, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+def _on_dev(w):
+    """Oracle weights on the GPU.  The oracle GRAPH (oracle/wan_oracle.py; its host evaluation is pinned to the reference's
+    goldens by tests/test_oracle_vs_golden.py) is evaluated by torch eager on the device in this file: the host evaluation of
+    the full-size cases costs minutes per test on a box with few cores (GPUTEST_r02 timed out on exactly that).  Tables
+    (sinusoid, RoPE, scheduler) are still built on the host inside the oracle."""
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in w.items()}
 
 
 def _tiny():
@@ -144,7 +152,7 @@ def test_rolling_cache_matches_reference_golden(golden):
 
 def test_production_width_layer_matches_oracle():
     """One 1.3B-width layer stack (d=1536, H=12, ffn=8960, L=2) at the real token count against the CPU
-    oracle run on the host cores (bf16 eager restatement of the reference)."""
+    oracle graph (bf16 eager restatement of the reference, evaluated by torch on the device)."""
     from oracle import wan_oracle as wo
     cfg = dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=2, freq_dim=256, text_len=512, eps=1e-6,
                num_frame_per_block=3)
@@ -153,9 +161,9 @@ def test_production_width_layer_matches_oracle():
     lat = torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
     ctx = torch.randn(40, 256, generator=g).to(torch.bfloat16)
     t = torch.tensor([[713.0, 713.0, 713.0]])
-    kvc = wo.initialize_kv_cache(2, 1, 9360, 12, 128, torch.bfloat16)
-    cac = wo.initialize_crossattn_cache(2, 1, 12, 128, torch.bfloat16)
-    ref, ref_x0 = wo.wrapper_forward(w, cfg, wo.FlowMatchScheduler(), lat, [ctx], t, kvc, cac, 0)
+    kvc = wo.initialize_kv_cache(2, 1, 9360, 12, 128, torch.bfloat16, DEV)
+    cac = wo.initialize_crossattn_cache(2, 1, 12, 128, torch.bfloat16, device=DEV)
+    ref, ref_x0 = wo.wrapper_forward(_on_dev(w), cfg, wo.FlowMatchScheduler(), lat.to(DEV), [ctx.to(DEV)], t.to(DEV), kvc, cac, 0)
     model, wr = _build(cfg, 256, w)
     kv, ca = _caches(cfg, 9360)
     flow, x0 = wr(lat.to(DEV), {"prompt_embeds": [ctx.to(DEV)]}, t.to(DEV), kv, ca, current_start=0)
@@ -164,15 +172,48 @@ def test_production_width_layer_matches_oracle():
     assert rel_l2(kv[1]["k"][0, :4680].cpu(), kvc[1]["k"][0, :4680]) <= 2e-2
 
 
+def test_full_width_14b_layer_matches_reference_golden(golden):
+    """BASELINE config 3 at production width against the REFERENCE ITSELF: tests/golden/dit_full_width_layer.pt is the upstream
+    CausalWanModel (dim 5120, 40 heads, ffn 13824, one layer; bf16 on the host cores, SDPA fallback) run by
+    oracle/make_golden.py full_width on the same seeded inputs: M = 4680 tokens at cache offset 4680 over a 9360-row window
+    whose first half holds earlier K/V.  rel-L2 <= 2e-2 on flow / x0 / the new K and V rows (sampled every 97th row),
+    indices exact, earlier rows untouched.  (The oracle port is bit-identical to the reference on this case: the golden
+    records port_vs_reference_rel_l2 = 0.)"""
+    from oracle import wan_oracle as wo
+    gold = golden("dit_full_width_layer.pt")
+    assert gold["port_vs_reference_rel_l2"] <= 1e-6
+    cfg = dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, freq_dim=256, text_len=512, eps=1e-6,
+               num_frame_per_block=3)
+    w = wo.make_weights(cfg, seed=5, text_dim=256)
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
+    ctx = torch.randn(40, 256, generator=g).to(torch.bfloat16)
+    t = torch.tensor([[713.0, 713.0, 713.0]])
+    old_k = torch.randn(1, 4680, 40, 128, generator=g).to(torch.bfloat16)
+    old_v = torch.randn(1, 4680, 40, 128, generator=g).to(torch.bfloat16)
+    model, wr = _build(cfg, 256, w)
+    kv, ca = _caches(cfg, 9360)
+    kv[0]["k"][:, :4680], kv[0]["v"][:, :4680] = old_k.to(DEV), old_v.to(DEV)
+    kv[0]["global_end_index"] = kv[0]["local_end_index"] = 4680
+    flow, x0 = wr(lat.to(DEV), {"prompt_embeds": [ctx.to(DEV)]}, t.to(DEV), kv, ca, current_start=4680)
+    assert int(kv[0]["local_end_index"]) == gold["local_end_index"] == 9360
+    assert int(kv[0]["global_end_index"]) == gold["global_end_index"] == 9360
+    assert rel_l2(flow.cpu(), gold["flow"]) <= 2e-2 and rel_l2(x0.cpu(), gold["x0"]) <= 2e-2
+    assert rel_l2(kv[0]["k"][0, 4680::97].cpu(), gold["k_new"]) <= 2e-2
+    assert rel_l2(kv[0]["v"][0, 4680::97].cpu(), gold["v_new"]) <= 2e-2
+    assert torch.equal(kv[0]["k"][0, :4680].cpu(), old_k[0])
+    assert abs(float(kv[0]["k"][0, :4680].double().abs().sum()) - gold["k_old_checksum"]) <= 1e-6 * gold["k_old_checksum"]
+
+
 def test_full_width_14b_layer_matches_oracle_and_fp32_gold():
     """BASELINE config 3 at production width against the ORACLE (not against itself): one layer of the 14B architecture
     (d 5120, 40 heads, ffn 13824) inside the full forward (patch / time / text embeddings, head), M = 4680 query tokens at
-    cache offset 4680 over a 9360-row window whose first half holds earlier K/V - vs the bf16 eager oracle on the host cores
-    (rel-L2 <= 2e-2) and vs the fp32 gold graph (error within 2x the bf16 oracle's own error)."""
+    cache offset 4680 over a 9360-row window whose first half holds earlier K/V - vs the bf16 eager oracle graph (rel-L2 <= 2e-2)
+    and vs the fp32 gold graph (error within 2x the bf16 oracle's own error).  Both oracle graphs are evaluated by torch eager on
+    the device (see _on_dev); the test above holds the same case to the reference's own host evaluation."""
     from oracle import wan_oracle as wo
     cfg = dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=1, freq_dim=256, text_len=512, eps=1e-6,
                num_frame_per_block=3)
-    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))   # the cores this process may use
     w = wo.make_weights(cfg, seed=5, text_dim=256)
     g = torch.Generator().manual_seed(11)
     lat = torch.randn(1, 3, 16, 60, 104, generator=g).to(torch.bfloat16)
@@ -182,18 +223,20 @@ def test_full_width_14b_layer_matches_oracle_and_fp32_gold():
     old_v = torch.randn(1, 4680, 40, 128, generator=g).to(torch.bfloat16)
 
     def prefilled(dtype):
-        kv = wo.initialize_kv_cache(1, 1, 9360, 40, 128, dtype)
-        kv[0]["k"][:, :4680], kv[0]["v"][:, :4680] = old_k.to(dtype), old_v.to(dtype)
+        kv = wo.initialize_kv_cache(1, 1, 9360, 40, 128, dtype, DEV)
+        kv[0]["k"][:, :4680], kv[0]["v"][:, :4680] = old_k.to(DEV, dtype), old_v.to(DEV, dtype)
         kv[0]["global_end_index"] = kv[0]["local_end_index"] = 4680
-        return kv, wo.initialize_crossattn_cache(1, 1, 40, 128, dtype)
+        return kv, wo.initialize_crossattn_cache(1, 1, 40, 128, dtype, device=DEV)
 
     with torch.inference_mode():
         kvr, car = prefilled(torch.bfloat16)
-        ref, ref_x0 = wo.wrapper_forward(w, cfg, wo.FlowMatchScheduler(), lat, [ctx], t, kvr, car, 4680)
+        wd = _on_dev(w)
+        ref, ref_x0 = wo.wrapper_forward(wd, cfg, wo.FlowMatchScheduler(), lat.to(DEV), [ctx.to(DEV)], t.to(DEV), kvr, car, 4680)
         kvg, cag = prefilled(torch.float32)
-        gold, _ = wo.wrapper_forward({k: v.float() for k, v in w.items()}, cfg, wo.FlowMatchScheduler(), lat.float(),
-                                     [ctx.float()], t, kvg, cag, 4680,
+        gold, _ = wo.wrapper_forward({k: v.float() for k, v in wd.items()}, cfg, wo.FlowMatchScheduler(), lat.float().to(DEV),
+                                     [ctx.float().to(DEV)], t.to(DEV), kvg, cag, 4680,
                                      attn_fn=lambda q, k, v: wo.attention_sdpa(q, k, v, dtype=None))
+        del wd, kvg, cag
     assert kvr[0]["local_end_index"] == 9360
     model, wr = _build(cfg, 256, w)
     kv, ca = _caches(cfg, 9360)
@@ -221,7 +264,7 @@ def test_session_block_loop_matches_oracle():
     g = torch.Generator().manual_seed(5)
     ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
     noise = torch.randn(1, 6, 16, 60, 104, generator=g).to(torch.bfloat16)
-    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9)
+    ora = wo.SessionOracle(_on_dev(w), cfg, [ctx.to(DEV)], noise.to(DEV), kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9)
     ref_blocks = [ora.generate_block().clone() for _ in range(2)]
 
     model, wr = _build(cfg, text_dim, w)
@@ -257,7 +300,7 @@ def test_session_at_another_resolution_uses_its_own_frame_length(monkeypatch):
     g = torch.Generator().manual_seed(6)
     ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
     noise = torch.randn(1, 9, 16, 30, 52, generator=g).to(torch.bfloat16)
-    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9)
+    ora = wo.SessionOracle(_on_dev(w), cfg, [ctx.to(DEV)], noise.to(DEV), kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9)
     ref_blocks = [ora.generate_block().clone() for _ in range(3)]
     model, wr = _build(cfg, text_dim, w)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
@@ -315,7 +358,7 @@ def test_session_first_frame_reencode_path():
     """keep_first_frame=False (the reference default): from block 2 on, get_clean_context_frames re-encodes the oldest
     pixel frame of the context window through the VAE encoder (release_server.py:572-575).  The re-encoded latent is
     checked against the encoder oracle (eager fp16 on this GPU) on the same pixel frame; the DiT blocks are checked
-    against the CPU session oracle fed with that latent."""
+    against the session oracle fed with that latent."""
     from oracle import vae_oracle as vo
     from oracle import wan_oracle as wo
     from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
@@ -364,8 +407,8 @@ def test_session_first_frame_reencode_path():
     mu_ref, _ = vo.encoder_wrapper_forward(w16, frames, [None] * 55, stream=False)
     assert rel_l2(mu.float(), mu_ref.float()) <= 2e-2
 
-    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9,
-                           first_frame_fn=lambda idx: mu.permute(0, 2, 1, 3, 4).cpu().to(torch.bfloat16))
+    ora = wo.SessionOracle(_on_dev(w), cfg, [ctx.to(DEV)], noise.to(DEV), kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=9,
+                           first_frame_fn=lambda idx: mu.permute(0, 2, 1, 3, 4).to(torch.bfloat16))
     for b in range(3):
         ref = ora.generate_block()
         assert rel_l2(sess.all_latents[:, 3 * b:3 * b + 3].cpu(), ref) <= 5e-2, b
@@ -374,7 +417,7 @@ def test_session_first_frame_reencode_path():
 def test_session_long_context_kv_cache_num_frames_9():
     """BASELINE config 5's context length: kv_cache_num_frames = 9 (Lkv = 18720, recompute over up to 9 context frames
     = 14040 tokens with the block-causal mask over three 3-frame blocks).  Four blocks on the tiny model with
-    keep_first_frame=True vs the CPU session oracle: block 3 recomputes over all nine earlier frames."""
+    keep_first_frame=True vs the session oracle: block 3 recomputes over all nine earlier frames."""
     from oracle import wan_oracle as wo
     from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
     from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
@@ -384,7 +427,7 @@ def test_session_long_context_kv_cache_num_frames_9():
     g = torch.Generator().manual_seed(15)
     ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
     noise = torch.randn(1, 12, 16, 60, 104, generator=g).to(torch.bfloat16)
-    ora = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=9, num_steps=2, shift=5.0, seed=4)
+    ora = wo.SessionOracle(_on_dev(w), cfg, [ctx.to(DEV)], noise.to(DEV), kv_cache_num_frames=9, num_steps=2, shift=5.0, seed=4)
     model, wr = _build(cfg, text_dim, w)
     pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 500]), DEV, generator=wr,
                                    text_encoder=None, vae=None)
@@ -408,7 +451,7 @@ def test_session_webcam_v2v_and_prompt_interpolation():
     """Streaming video-to-video (release_server.py:489-527, :651-657): block 0 encodes 9 pushed frames on fresh encoder
     caches (chunks 1+4+4), block 1 encodes 12 with stream=True; denoising starts from latents noised to the first step's
     level.  Checked: the encoded latents vs the encoder oracle (eager fp16 on this GPU, same cache continuation), the DiT
-    blocks vs the CPU session oracle started from the same noisy latents, and a prompt interpolation that re-initialises
+    blocks vs the session oracle started from the same noisy latents, and a prompt interpolation that re-initialises
     the cross-attention cache (:459-468, :662-666)."""
     from oracle import vae_oracle as vo
     from oracle import wan_oracle as wo
@@ -470,8 +513,9 @@ def test_session_webcam_v2v_and_prompt_interpolation():
     assert len(sess.interpolated_prompt_embeds) == 1 and torch.equal(sess.interpolated_prompt_embeds[0][0, :64].cpu(), ctx[1])
     assert all(c["is_init"] for c in pipe.crossattn_cache)
 
-    # DiT side vs the CPU oracle, started from the same noisy latents (the oracle reads them from its noise tensor)
-    ora = wo.SessionOracle(w, cfg, [ctx[0]], torch.cat(noisy, dim=1), kv_cache_num_frames=3, num_steps=2, shift=5.0, seed=1)
+    # DiT side vs the oracle, started from the same noisy latents (the oracle reads them from its noise tensor)
+    ora = wo.SessionOracle(_on_dev(w), cfg, [ctx[0].to(DEV)], torch.cat(noisy, dim=1).to(DEV), kv_cache_num_frames=3, num_steps=2,
+                           shift=5.0, seed=1)
     ora.denoising_step_list = sess.denoising_step_list.cpu()
     for b in range(2):
         if b == 1:   # prompt switch AFTER the KV recompute (which still sees the old prompt's cross-attention cache)
@@ -479,7 +523,7 @@ def test_session_webcam_v2v_and_prompt_interpolation():
 
             def recompute_then_switch():
                 start = orig_recompute()
-                ora.prompt_embeds = [ctx[0]]          # lerp weight 0: same prompt, but the cache is rebuilt
+                ora.prompt_embeds = [ctx[0].to(DEV)]  # lerp weight 0: same prompt, but the cache is rebuilt
                 for c in ora.crossattn_cache:
                     c["is_init"] = False
                 return start
@@ -503,7 +547,8 @@ def test_config1_320x192_native_block_and_vae():
     g = torch.Generator().manual_seed(2)
     noise = torch.randn(1, 3, 16, 24, 40, generator=g).to(torch.bfloat16)
     ctx = torch.randn(16, 64, generator=g).to(torch.bfloat16)
-    ref = wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=1, shift=5.0, seed=0).generate_block()
+    ref = wo.SessionOracle(_on_dev(w), cfg, [ctx.to(DEV)], noise.to(DEV), kv_cache_num_frames=3, num_steps=1, shift=5.0,
+                           seed=0).generate_block()
     m = CausalWanModel(dim=1536, ffn_dim=8960, num_heads=12, num_layers=1, text_dim=64, freq_dim=256, device=DEV)
     m.load_state_dict(w)
     wr = WanDiffusionWrapper(m, timestep_shift=5.0)
@@ -533,14 +578,15 @@ def test_fp8_forward_matches_fp8_oracle():
     w8[wo.FP8_FLAG] = True
     lat, ctx = tiny_inputs()
     sched = wo.FlowMatchScheduler()
-    kvc = wo.initialize_kv_cache(cfg["num_layers"], 1, 9360, cfg["num_heads"], 128, torch.bfloat16)
-    cac = wo.initialize_crossattn_cache(cfg["num_layers"], 1, cfg["num_heads"], 128, torch.bfloat16)
+    kvc = wo.initialize_kv_cache(cfg["num_layers"], 1, 9360, cfg["num_heads"], 128, torch.bfloat16, DEV)
+    cac = wo.initialize_crossattn_cache(cfg["num_layers"], 1, cfg["num_heads"], 128, torch.bfloat16, device=DEV)
+    w8, ctx_d, lat_d = _on_dev(w8), ctx.to(DEV), [x.to(DEV) for x in lat]
     t = torch.ones([1, 3], dtype=torch.int64) * 700
     t0 = torch.zeros([1, 3], dtype=torch.int64)
-    ref_a, _ = wo.wrapper_forward(w8, cfg, sched, lat[0], [ctx], t, kvc, cac, 0)
+    ref_a, _ = wo.wrapper_forward(w8, cfg, sched, lat_d[0], [ctx_d], t.to(DEV), kvc, cac, 0)
     wo.reset_kv_cache(kvc)
-    ref_rc, _ = wo.wrapper_forward(w8, cfg, sched, lat[2], [ctx], t0, kvc, cac, 4680, recompute=True)
-    ref_b, _ = wo.wrapper_forward(w8, cfg, sched, lat[3], [ctx], t, kvc, cac, 4680)
+    ref_rc, _ = wo.wrapper_forward(w8, cfg, sched, lat_d[2], [ctx_d], t0.to(DEV), kvc, cac, 4680, recompute=True)
+    ref_b, _ = wo.wrapper_forward(w8, cfg, sched, lat_d[3], [ctx_d], t.to(DEV), kvc, cac, 4680)
 
     outs = {}
     for mode in ("bf16", "fp8"):
@@ -584,12 +630,13 @@ def test_fp8_context_parallel_matches_row_sharded_fp8_oracle(exchange):
     w8[wo.FP8_ROW_SHARDS] = (2, 4680)
     lat, ctx = tiny_inputs()
     sched = wo.FlowMatchScheduler()
-    kvc = wo.initialize_kv_cache(cfg["num_layers"], 1, 9360, cfg["num_heads"], 128, torch.bfloat16)
-    cac = wo.initialize_crossattn_cache(cfg["num_layers"], 1, cfg["num_heads"], 128, torch.bfloat16)
+    kvc = wo.initialize_kv_cache(cfg["num_layers"], 1, 9360, cfg["num_heads"], 128, torch.bfloat16, DEV)
+    cac = wo.initialize_crossattn_cache(cfg["num_layers"], 1, cfg["num_heads"], 128, torch.bfloat16, device=DEV)
+    w8, ctx_d, lat_d = _on_dev(w8), ctx.to(DEV), [x.to(DEV) for x in lat]
     t = torch.ones([1, 3], dtype=torch.int64) * 700
     t0 = torch.zeros([1, 3], dtype=torch.int64)
-    ref_rc, _ = wo.wrapper_forward(w8, cfg, sched, lat[2], [ctx], t0, kvc, cac, 4680, recompute=True)
-    ref_b, _ = wo.wrapper_forward(w8, cfg, sched, lat[3], [ctx], t, kvc, cac, 4680)
+    ref_rc, _ = wo.wrapper_forward(w8, cfg, sched, lat_d[2], [ctx_d], t0.to(DEV), kvc, cac, 4680, recompute=True)
+    ref_b, _ = wo.wrapper_forward(w8, cfg, sched, lat_d[3], [ctx_d], t.to(DEV), kvc, cac, 4680)
     outs = []
     for cp in (SimulatedContextParallel(2, exchange), None):
         model, wr = _build(cfg, text_dim, w)
