@@ -268,10 +268,14 @@ def main():
         downloader = FrameDownloader(dev, slots=2)
     tickets = []
 
+    wait_s = [0.0]      # host time spent WAITING for the previous block's frames (a sync with the GPU, not launch issue)
+
     def deliver(pixels, frame_ids, event):
         if downloader is not None:
             if tickets:
+                tw = time.perf_counter()
                 downloader.fetch(tickets.pop())
+                wait_s[0] += time.perf_counter() - tw
             tickets.append(downloader(pixels, frame_ids, event))
 
     sess = GenerationSession(params, models, frame_callback=deliver, device=dev)
@@ -288,6 +292,7 @@ def main():
     ops.prof_enable(args.profile_classes != "none",
                     None if args.profile_classes == "all" else [c for c in args.profile_classes.split(",") if c != "none"])
     wr.on = True
+    wait_s[0] = 0.0
     t0 = time.perf_counter()
     frames = 0
     for _ in range(args.steps):
@@ -298,8 +303,11 @@ def main():
         downloader.fetch(tickets.pop())
     barrier()
     elapsed = time.perf_counter() - t0
-    print(f"[bench] rank {rank}: host issue time {1e3 * host_issue_s / args.steps:.1f} ms per block of {1e3 * elapsed / args.steps:.1f} ms",
-          file=sys.stderr)
+    # the loop fetches block n-1's frames while block n is queued: that fetch blocks until the GPU has finished block n-1, so
+    # the loop's wall time is mostly that wait; what is left is the host's own work (Python session loop + ctypes launches)
+    print(f"[bench] rank {rank}: host loop {1e3 * host_issue_s / args.steps:.1f} ms per block of {1e3 * elapsed / args.steps:.1f} ms, "
+          f"of which {1e3 * wait_s[0] / args.steps:.1f} ms waiting for the previous block's frames -> "
+          f"launch issue {1e3 * (host_issue_s - wait_s[0]) / args.steps:.1f} ms per block", file=sys.stderr)
     ops.prof_enable(False)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)

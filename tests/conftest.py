@@ -39,6 +39,15 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _torch_reference_convs_without_miopen():
+    """The torch REFERENCE convolutions of the GPU tests (F.conv3d / conv2d in fp32, the oracle graphs evaluated on the
+    device) run on torch's native vol2col + GEMM path: on a fresh box MIOpen compiles a kernel per new shape (190 s for
+    the full-resolution VAE oracle graph in the r03 dry run).  The product path never calls a torch convolution."""
+    with torch.backends.cudnn.flags(enabled=False):
+        yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

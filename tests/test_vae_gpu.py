@@ -351,7 +351,7 @@ def test_full_resolution_streaming_decode_matches_fp32_oracle():
     """The decoder at the benchmarked size against the ORACLE: latents 60 x 104 -> 480 x 832 pixels, a first call on fresh
     caches (2 latent frames -> 1 + 4 pixel frames) and a streamed second call on the returned caches (1 latent frame -> 4
     frames), vs `vae_oracle.decoder_wrapper_forward` in fp32.  The oracle graph is evaluated by torch on the GPU here (fp32
-    eager, MIOpen convolutions): on the host cores the same three latent frames cost 4-25 minutes depending on the box, and
+    eager, torch's native convolutions): on the host cores the same three latent frames cost 4-25 minutes depending on the box, and
     the CPU evaluation of this oracle is what the small-size tests pin to the reference golden
     (test_vae_oracle_vs_golden.py, test_streaming_decoder_matches_reference_golden).  Tolerances of the golden test above:
     max-abs within 2x the error of the same graph in eager fp16 (the reference's precision) with a 2e-2 floor, hard cap
