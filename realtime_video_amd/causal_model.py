@@ -107,6 +107,9 @@ class _SelfAttnHandle:
         # fixed at construction like the reference (causal_model.py:192): later writes to local_attn_size
         # (release_server.py:544-546 sets -1) do not change the attention window
         self.max_attention_size = 32760 if local_attn_size == -1 else local_attn_size * 1560
+        # the same window in FRAMES (32760 = 21 frames of 1560 tokens): at another resolution the session's caches are sized in
+        # that resolution's tokens per frame, and a window of max_attention_size tokens would cut mid-frame
+        self.window_frames = 21 if local_attn_size == -1 else local_attn_size
 
     def fuse_projections(self):
         self.fused_projections = True
@@ -392,7 +395,7 @@ class CausalWanModel:
         local_start = local_end - num_new
         if local_start < 0 or local_end > kv_size:
             raise RuntimeError(f"KV cache window [{local_start}, {local_end}) outside cache of {kv_size} rows")
-        lo = max(0, local_end - sa.max_attention_size)
+        lo = max(0, local_end - (sa.max_attention_size if frame_seqlen == 1560 else sa.window_frames * frame_seqlen))
         if ring_start == 0:
             ring_lo = ring_size = 0         # unrotated: logical == physical
 

@@ -400,6 +400,13 @@ extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, 
     if (!ups) return set_error(-1, "conv: row windows are for the upsampling stage transition");
     if (in_rows <= 0 || img_rows <= 0 || y_out0 < 0 || y_in0 < 0 || y_out0 + H > img_rows)
       return set_error(-1, "conv: bad row window");
+    {  // every tap row of the window (upsampled rows y_out0 - 1 .. y_out0 + H, clipped to the image) must lie inside the
+       // supplied source rows [y_in0, y_in0 + in_rows): the kernel does not clamp source rows
+      const int lo_up = y_out0 > 0 ? y_out0 - (kh >> 1) : 0;
+      const int hi_up = y_out0 + H - 1 + (kh >> 1) < img_rows ? y_out0 + H - 1 + (kh >> 1) : img_rows - 1;
+      if ((lo_up >> 1) < y_in0 || (hi_up >> 1) >= y_in0 + in_rows)
+        return set_error(-1, "conv: the row window's taps fall outside the supplied input rows");
+    }
     p.y_out0 = y_out0;
     p.y_in0 = y_in0;
     p.in_rows = in_rows;

@@ -132,9 +132,36 @@ def ensure_gemm_workspace(device, stream=None):
     with torch.cuda.device(idx):
         ws = torch.zeros(n + 256, dtype=torch.uint8, device=torch.device("cuda", idx))
         off = (-ws.data_ptr()) % 256
-        _lib.call("rtv_gemm_set_stream_workspace", ctypes.c_void_p(int(stream)), ctypes.c_void_p(ws.data_ptr() + off),
-                  ctypes.c_size_t(n))
+        try:
+            _lib.call("rtv_gemm_set_stream_workspace", ctypes.c_void_p(int(stream)), ctypes.c_void_p(ws.data_ptr() + off),
+                      ctypes.c_size_t(n))
+        except RuntimeError as e:
+            if "too many workspaces" not in str(e):
+                raise
+            # the library's table (64 streams over all devices) is full: GEMMs on this stream run WITHOUT split-K (same
+            # results up to fp32 association, a few per cent slower on partial tile rounds) instead of failing the forward
+            import warnings
+            warnings.warn("rtv: split-K workspace table full; GEMMs on this stream run unsplit "
+                          "(release_gemm_workspace() frees the entry of a stream that is no longer used)")
+            ws = None
     _gemm_ws[key] = ws
+
+
+def release_gemm_workspace(device, stream):
+    """Detach and free the split-K workspace of a stream that will not launch GEMMs any more (e.g. before it is destroyed).
+    Waits for the stream first: a launch still in flight may be using the slabs."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    handle = int(stream.cuda_stream if hasattr(stream, "cuda_stream") else stream)
+    ws = _gemm_ws.pop((idx, handle), None)
+    if ws is None:
+        return
+    with torch.cuda.device(idx):
+        if hasattr(stream, "synchronize"):
+            stream.synchronize()
+        else:
+            torch.cuda.synchronize(idx)
+        _lib.call("rtv_gemm_set_stream_workspace", ctypes.c_void_p(handle), ctypes.c_void_p(0), ctypes.c_size_t(0))
 
 
 def gemm(a, w, bias=None, act=ACT_NONE, gate=None, gate_stride=0, rows_per_frame=0, residual=None,

@@ -46,7 +46,9 @@ class FlowMatchScheduler:
 
     def add_noise(self, original_samples, noise, timestep):
         if (noise.is_cuda and noise.ndim == 4 and noise.dtype == torch.bfloat16 and original_samples.dtype == torch.bfloat16
-                and original_samples.shape == noise.shape and timestep.ndim == 1 and timestep.dtype in _ops()._T_KIND):
+                and original_samples.shape == noise.shape and timestep.ndim == 1 and timestep.dtype in _ops()._T_KIND
+                and timestep.numel() == noise.shape[0]            # a 1-element timestep broadcasts in the chain below
+                and self.timesteps.dtype == torch.float32 and self.sigmas.dtype == torch.float32):
             self.to(noise.device)   # one launch: lookup + blend (csrc/scheduler.hip), same roundings as the chain below
             return _ops().scheduler_step(self.timesteps, self.sigmas, x0=original_samples, noise=noise,
                                          t_next=timestep.to(noise.device).contiguous())[1]

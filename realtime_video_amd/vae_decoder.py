@@ -290,25 +290,35 @@ class CacheArenas:
     storage address of its first slot; a list whose slots were cloned / moved (no longer views of a known arena) gets a new
     arena with the slot contents copied in, and a list that belongs to another frame size is refused."""
 
-    KEEP = 4
+    KEEP = 8          # concurrent streams per wrapper whose arenas stay registered (least recently used goes first)
 
-    def __init__(self):
+    def __init__(self, keep=None):
         self._by_ptr = {}
+        self.keep = int(keep) if keep is not None else self.KEEP
 
     def register(self, views, arena, base, size):
-        # The entry holds the arena, so its address cannot be reused while it is listed; only the last few streams are
-        # kept (an evicted stream that comes back takes the copy-in path below).
+        # The entry holds the arena, so its address cannot be reused while it is listed.  An evicted stream that comes back
+        # takes the copy-in path of lookup() (correct, but 55 slot copies + a new arena): warn, it is a performance cliff.
         self._by_ptr[views[0].data_ptr()] = (arena, base, size)
-        while len(self._by_ptr) > self.KEEP:
+        while len(self._by_ptr) > self.keep:
             self._by_ptr.pop(next(iter(self._by_ptr)))
+            import warnings
+            warnings.warn(f"rtv: more than {self.keep} concurrent feature-cache streams on one VAE wrapper; the least recently "
+                          "used arena was dropped (raise CacheArenas.KEEP / the wrapper's cache_streams)")
 
     def lookup(self, cache, size, new_arena, make_views):
         """`cache` (a list, updated in place when it has to be rebuilt) -> (arena, base)."""
-        ent = self._by_ptr.get(cache[0].data_ptr())
+        key = cache[0].data_ptr()
+        ent = self._by_ptr.get(key)
         if ent is not None:
-            if ent[2] != size:
-                raise ValueError(f"feature cache belongs to a {ent[2]} stream, this call is {size}")
-            return ent[0], ent[1]
+            lo, hi = ent[0].data_ptr(), ent[0].data_ptr() + ent[0].numel() * ent[0].element_size()
+            # a hit only if EVERY slot still is a view of that arena (a restored snapshot may have replaced some of them:
+            # their contents must not be ignored -> copy-in path below)
+            if all(c is None or lo <= c.data_ptr() < hi for c in cache):
+                if ent[2] != size:
+                    raise ValueError(f"feature cache belongs to a {ent[2]} stream, this call is {size}")
+                self._by_ptr[key] = self._by_ptr.pop(key)      # most recently used
+                return ent[0], ent[1]
         arena = new_arena()
         base = (-arena.data_ptr()) % 256
         views = make_views(arena, base)       # registers the new arena

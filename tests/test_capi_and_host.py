@@ -434,9 +434,22 @@ def test_vae_cache_arena_registry_finds_rebuilds_and_refuses():
     bad[2] = torch.zeros(5, dtype=torch.float16)
     with pytest.raises(ValueError):
         reg.lookup(bad, (8, 12), new_arena, lambda a, b: make_views(a, b, reg, (8, 12)))
-    # eviction: only KEEP arenas stay registered
-    keep = []
-    for _ in range(CacheArenas.KEEP + 2):
+    # a restored snapshot that replaced SOME slots (slot 0 still a view of the old arena): the replaced contents must not be
+    # ignored -> copy-in path, not a hit on the old arena
+    mixed = list(views)
+    mixed[1] = torch.full_like(views[1], 7.0)
+    n_made = len(made)
+    a3, _ = reg.lookup(mixed, (8, 12), new_arena, lambda a, b: make_views(a, b, reg, (8, 12)))
+    assert len(made) == n_made + 1 and a3 is made[-1]
+    assert float(mixed[1][0]) == 7.0 and torch.equal(mixed[0], views[0]) and mixed[0].data_ptr() != views[0].data_ptr()
+    # eviction: only `keep` arenas stay registered, least recently USED first (a hit refreshes an entry), with a warning
+    reg = CacheArenas(keep=3)
+    lists = []
+    for i in range(3):
         a = torch.zeros(64 + 256, dtype=torch.uint8)
-        keep.append(make_views(a, 0, reg, (8, 12)))
-    assert len(reg._by_ptr) == CacheArenas.KEEP
+        lists.append(make_views(a, 0, reg, (8, 12)))
+    reg.lookup(list(lists[0]), (8, 12), None, None)               # stream 0 is now the most recently used
+    with pytest.warns(UserWarning, match="concurrent feature-cache streams"):
+        lists.append(make_views(torch.zeros(64 + 256, dtype=torch.uint8), 0, reg, (8, 12)))
+    assert len(reg._by_ptr) == 3
+    assert lists[0][0].data_ptr() in reg._by_ptr and lists[1][0].data_ptr() not in reg._by_ptr

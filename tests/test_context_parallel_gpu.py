@@ -1,6 +1,7 @@
 """Two real processes driving the context-parallel path (ContextParallel + phase API + row-sharded VAE decode + HIP
-kernels) on the MI355X.  The test box has ONE GPU, so both ranks share cuda:0 and the collective runs over gloo (staged
-through the host); on a multi-GPU node the identical code path runs over RCCL (bench.py --gpus N)."""
+kernels) on the MI355X.  On a ONE-GPU box both ranks share cuda:0 and the collectives run over gloo (staged through the
+host); the `nccl` variants run the identical session with one GPU per rank over RCCL / xGMI and skip themselves when fewer
+than two GPUs are visible - a multi-GPU driver runs them unmodified (bench.py --gpus N is the same code path)."""
 import os
 import socket
 
@@ -20,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run_session(cp):
+def _run_session(cp, dev="cuda:0"):
     from oracle import wan_oracle as wo
     from oracle.make_golden import TEXT_DIM, TINY
     from realtime_video_amd.causal_model import CausalWanModel
@@ -30,7 +31,6 @@ def _run_session(cp):
     from realtime_video_amd.vae_decoder import VAEDecoderWrapper
     from realtime_video_amd.vae_encoder import VAEEncoderWrapper
     from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
-    dev = "cuda:0"
     cfg = dict(TINY)
     w = wo.make_weights(cfg, seed=0, text_dim=TEXT_DIM)
     model = CausalWanModel(dim=cfg["dim"], ffn_dim=cfg["ffn_dim"], num_heads=cfg["num_heads"],
@@ -63,12 +63,15 @@ def _run_session(cp):
     return [o.cpu() for o in outs] + [sess.all_latents.cpu()], pipe.kv_cache1[1]["k"].cpu()
 
 
-def _worker(rank, world, port, exchange, ret):
+def _worker(rank, world, port, exchange, backend, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes)
+    dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from realtime_video_amd.parallel import ContextParallel
-        outs, k = _run_session(ContextParallel(exchange=exchange))
+        outs, k = _run_session(ContextParallel(exchange=exchange), dev)
         ret[rank] = (outs, k)
         if os.environ.get("RTV_DBG_ENC"):
             ret[f"enc{rank}"] = list(_run_session.rec)
@@ -76,13 +79,17 @@ def _worker(rank, world, port, exchange, ret):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
 @pytest.mark.parametrize("exchange", ["rows", "heads"])
-def test_two_process_context_parallel_session_equals_single_process(exchange):
+def test_two_process_context_parallel_session_equals_single_process(exchange, backend):
     """exchange="rows": K/V all-gather into replicated caches; "heads": all-to-all pair, every rank holding only its own
-    heads of the KV cache (allocated head-sharded by the pipeline's cache manager)."""
+    heads of the KV cache (allocated head-sharded by the pipeline's cache manager).  backend "nccl": one GPU per rank,
+    RCCL collectives on the communication stream overlapped with the projections (needs >= 2 GPUs)."""
     world = 2
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        pytest.skip(f"RCCL variant needs {world} GPUs, {torch.cuda.device_count()} visible")
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), exchange, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), exchange, backend, ret), nprocs=world, join=True)
     ref_outs, ref_k = _run_session(None)
     hn = ref_k.shape[2] // world
     for rank in range(world):

@@ -414,6 +414,29 @@ def test_gemm_fp8_matches_scaled_mm_restatement(ops, M, N, K):
     assert rel_l2(out, (a.float() @ w.float().t() + b.float())) <= 6e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(4680, 5120, 5120), (585, 15360, 5120), (300, 1536, 256)])
+def test_gemm_fp8_matches_torch_scaled_mm(ops, M, N, K):
+    """Independent pin of the fp8 weight path (release_server.py:179-182): torchao's Float8DynamicActivationFloat8WeightConfig
+    (PerTensor) quantises with scale = amax / 448, casts to e4m3 and calls `torch._scaled_mm(x_q, w_q.t(), scale_a, scale_b,
+    bias, out_dtype=x.dtype)`.  torchao itself is not in the image, but `torch._scaled_mm` - the third-party arithmetic at the
+    bottom of that path (hipBLASLt's e4m3 GEMM on gfx950) - is: the same e4m3 bytes and scales go through it and through
+    rtv_gemm_fp8.  Products of two e4m3 numbers are exact in fp32, so the two differ only by the fp32 accumulation order and
+    the final bf16 rounding: rel-L2 <= 2e-3, max-abs within one bf16 ulp of the largest output."""
+    if not hasattr(torch, "_scaled_mm"):
+        pytest.skip("torch._scaled_mm not available")
+    a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+    aq, sa = ops.quantize_fp8(a)
+    sw = (w.float().abs().max().clamp(min=1e-12) * (torch.tensor(1.0) / torch.tensor(448.0)).to(DEV)).reshape(1)
+    wq = (w.float() / sw).clamp(-448, 448).to(torch.float8_e4m3fn)
+    try:
+        ref = torch._scaled_mm(aq, wq.t(), scale_a=sa.reshape(()), scale_b=sw.reshape(()), bias=b, out_dtype=torch.bfloat16)
+    except (RuntimeError, TypeError) as e:                  # a build without fp8 GEMM support for this device
+        pytest.skip(f"torch._scaled_mm unavailable here: {str(e)[:120]}")
+    out = ops.gemm_fp8(aq, sa, wq, float(sw), bias=b)
+    assert rel_l2(out, ref) <= 2e-3
+    assert max_abs(out, ref) <= 2 ** -7 * float(ref.float().abs().max())
+
+
 def test_gemm_fp8_fused_epilogue(ops):
     M, N, K, F = 4680, 1536, 1536, 3
     a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
