@@ -110,6 +110,9 @@ def cpu_baseline(model_cfg, with_vae=True):
             t_vae = (time.time() - t0) * 3
     t_block = t_dit + (t_vae or 0.0)
     return {"value": 12.0 / t_block, "unit": "frames/s", "cores": cores, "kind": "port",
+            "port_vs_reference": "the Python reference cannot travel to the GPU box; the same sample on the upstream modules in "
+                                 "the authoring container costs what the port costs (port / reference = 1.03 DiT layer, 0.92 VAE "
+                                 "frame, outputs identical: profiles/r03_cpu_baseline_reference_vs_port.txt)",
             "sample": f"DiT: 1 layer at the benchmarked width (d={d}, ffn={ffn}, H={H}), M=4680 query tokens, 9360 cached keys, "
                       f"bf16 eager oracle, second of two runs {t_layer:.2f} s, extrapolated x{L} layers x 4.88 forwards per 12-frame "
                       f"block = {t_dit:.0f} s" + (f"; VAE: 1 latent frame (4 of 12 pixel frames) of the streaming decode at 480x832 "
@@ -127,9 +130,10 @@ def main():
     ap.add_argument("--denoising-steps", type=int, default=4)
     ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-classes", default="gemm,attn",
-                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm,attn' (the roofline kernel and "
-                         "the attention kernel, default), 'all' (diagnostic: every launch, costs a few %% of throughput) or 'none'")
+    ap.add_argument("--profile-classes", default="gemm,attn,conv",
+                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm,attn,conv' (the roofline kernel, "
+                         "the attention kernels and the VAE convolutions, default), 'all' (diagnostic: every launch, costs a few "
+                         "%% of throughput) or 'none'")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
                          "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
@@ -305,6 +309,8 @@ def main():
     elapsed = time.perf_counter() - t0
     # the loop fetches block n-1's frames while block n is queued: that fetch blocks until the GPU has finished block n-1, so
     # the loop's wall time is mostly that wait; what is left is the host's own work (Python session loop + ctypes launches)
+    host_ms = {"loop": 1e3 * host_issue_s / args.steps, "waiting_for_frames": 1e3 * wait_s[0] / args.steps,
+               "launch_issue": 1e3 * (host_issue_s - wait_s[0]) / args.steps}
     print(f"[bench] rank {rank}: host loop {1e3 * host_issue_s / args.steps:.1f} ms per block of {1e3 * elapsed / args.steps:.1f} ms, "
           f"of which {1e3 * wait_s[0] / args.steps:.1f} ms waiting for the previous block's frames -> "
           f"launch issue {1e3 * (host_issue_s - wait_s[0]) / args.steps:.1f} ms per block", file=sys.stderr)
@@ -365,6 +371,9 @@ def main():
                                     + prof["misc"]["ms"]) / (args.steps * fwd_per_block)
                                    if args.profile_classes == "all" else None),
             "kernel_ms_per_block": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"] > 0},
+            # host side of a block: the session loop's wall time, the part of it spent blocked on the previous block's frames
+            # (a wait on the GPU, not work) and the rest = Python + ctypes launch issue (6 ms under --hipgraph)
+            "host_ms_per_block": host_ms,
         },
         "roofline": {
             "kernel": "gemm8_kernel / gemm_kernel (bf16 MFMA projection GEMMs with fused epilogues: all DiT linears)",
