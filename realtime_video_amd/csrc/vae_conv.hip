@@ -312,6 +312,281 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------- halo-tile kernel (round 3)
+// The 3x3x3 stride-1 convolutions of the decoder's ResidualBlocks (wan/modules/vae.py:175-209) at 96 / 192 channels are 71 % of
+// the VAE's FLOPs.  conv_igemm_kernel gathers the im2col rows of every one of the 27 taps from global
+// memory again: 7 LDS-DMA instructions per 12 MFMAs and wave, issue-bound on staging (MFMA busy 28 %, profiles/r01_pmc_hot_kernels.txt).
+// Here a workgroup owns a 16 x 32 pixel tile of one frame x 96 filters and stages, per (time slice dt, 32-channel chunk), the
+// 18 x 34 HALO of that tile once (39 KiB, double buffered); the nine spatial taps of the chunk are then MFMAs whose A fragments
+// are ds_read_b128 at tap-shifted addresses of the same LDS image - 5 halo + 9 weight DMA instructions per 108 MFMAs and wave.
+//   * 8 waves, wave w = tile rows 2w, 2w+1 (two 32-pixel m-blocks) x 96 filters: 6 accumulator blocks, 12 MFMAs per tap;
+//   * weights stream per "tap row" (dt, chunk, dy): [dx][96 filters][32 channels] = 18 KiB through a 3-slot ring;
+//   * one raw s_barrier + one counted vmcnt per tap row (36 MFMAs per wave); every wave issues the same number of DMA
+//     instructions per step (the few surplus ones repeat a piece), so the counts are compile-time constants;
+//   * bank conflicts: a pixel / filter row is 64 bytes, its 16-byte chunk c sits at slot c ^ ((column >> 2) & 3) - keyed by the
+//     COLUMN only, so a tap's row shift is an immediate offset and its column shift one of three precomputed per-lane bases; the
+//     16 lanes of a quarter wave (16 consecutive columns) then cover all 16 slots of a 256-byte bank row.
+// K order per output pixel: (dt, chunk) outer, (dy, dx) inner - independent of the tile position, so row-sharded and
+// unsharded decodes stay bit-identical.
+namespace ch {
+constexpr int TH = 16, TW = 32, HPITCH = 34, HROWS = 18;
+constexpr int HPIX = HROWS * HPITCH;        // 612 halo pixels
+constexpr int HREAL = 39;                   // 1-KiB pieces (16 pixels x 64 bytes) that cover them
+constexpr int HBYTES = HREAL * 1024;
+constexpr int WROW_BYTES = 3 * 96 * 64;     // one tap row of weights: [dx][filter][32 channels]
+constexpr int WREAL = 18;
+constexpr int LDS_BYTES = 2 * HBYTES + 3 * WROW_BYTES;   // 135168
+constexpr int THREADS = 512;
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+template <int I, int N, typename F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(IC<I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+// Fragment read as inline asm: behind a pending LDS DMA the compiler's wait-count pass waits lgkmcnt(0) in front of the first
+// consumer of ANY plain LDS load (measured in the first build of this kernel: two full drains per tap row); the asm form is
+// invisible to it and the consumer side waits with a counted lgkmcnt that the fragment registers depend on.
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(uint32_t lds_addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
+  return r;
+}
+template <int CNT>
+__device__ __forceinline__ void lds_wait(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
+}
+}  // namespace ch
+
+__global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p, int tiles_x, int tiles_y) {
+  using namespace ch;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, gl = lane >> 5;
+
+  // workgroup -> (frame, tile, filter tile): the filter tiles of one pixel tile are neighbours (they share the halo through L2)
+  const int tiles_n = p.Cout / 96;
+  const int id = xcd_remap(blockIdx.x, p.T * tiles_y * tiles_x * tiles_n);
+  const int tn = id % tiles_n;
+  int rest = id / tiles_n;
+  const int tx = rest % tiles_x;
+  rest /= tiles_x;
+  const int ty = rest % tiles_y, t = rest / tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH, n0 = tn * 96;
+
+  const int cpk = p.Cin / 32;                      // channel chunks per time slice
+  const int G = 3 * cpk;                           // (dt, chunk) groups
+  const int slice = p.inH * p.inW * p.Cin;
+
+  // ---- halo DMA geometry: wave w issues pieces 5w .. 5w+4 (piece 39 repeats 38); lane -> halo pixel q = 16 piece + lane / 4,
+  //      LDS slot lane % 4, source chunk = slot ^ key(halo column)
+  int h_off[5], h_ok = 0, h_lds[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int piece = min(wave * 5 + i, HREAL - 1);
+    h_lds[i] = piece * 1024;
+    const int q = piece * 16 + (lane >> 2);
+    const int hr = q / HPITCH, hc = q - hr * HPITCH;
+    const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+    const bool ok = q < HPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const int c = (lane & 3) ^ ((hc >> 2) & 3);
+    h_off[i] = ((t * p.inH + y) * p.inW + x) * p.Cin + c * 8;
+    if (ok) h_ok |= 1 << i;
+  }
+  // ---- weight DMA geometry: wave w issues pieces 3w .. 3w+2 of the 18 (pieces 18..23 repeat 10..15); piece = (dx, 16 filters)
+  int w_off[3], w_lds[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int piece = wave * 3 + i;
+    if (piece >= WREAL) piece -= 8;
+    w_lds[i] = piece * 1024;
+    const int dx = piece / 6, f = (piece % 6) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((f >> 2) & 3);
+    w_off[i] = ((n0 + f) * 27 + dx) * p.Cin + c * 8;
+  }
+  auto issue_h = [&](int g, int i0, int i1) __attribute__((always_inline)) {   // pieces i0..i1-1 of group g's halo
+    g = min(g, G - 1);
+    const int dt = g / cpk, cb = g - dt * cpk;
+    const int uoff = dt * slice + cb * 32;
+    char* dst = smem + (g & 1) * HBYTES;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const uint16_t* src = ((h_ok >> i) & 1) ? p.in + (ptrdiff_t)(h_off[i] + uoff) : p.zeros;
+      dma16(src, dst + h_lds[i]);
+    }
+  };
+  auto issue_w = [&](int g, int dy, int slot) __attribute__((always_inline)) {  // tap row (g, dy) -> ring slot
+    const int gg = min(g, G - 1);
+    const int dt = gg / cpk, cb = gg - dt * cpk;
+    const int uoff = (dt * 9 + dy * 3) * p.Cin + cb * 32;
+    char* dst = smem + 2 * HBYTES + slot * WROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dma16(p.w + (ptrdiff_t)(w_off[i] + uoff), dst + w_lds[i]);
+  };
+
+  // ---- fragment read addresses (bytes inside a halo buffer / a weight ring slot)
+  int a_base[3][2], b_base[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hc = l31 + dx;
+      a_base[dx][ks] = ((2 * wave) * HPITCH + hc) * 64 + (((2 * ks + gl) ^ ((hc >> 2) & 3)) << 4);
+    }
+    b_base[ks] = l31 * 64 + (((2 * ks + gl) ^ ((l31 >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+#define CH_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // prologue: halo(0), W(0, dy 0), W(0, dy 1)
+  issue_h(0, 0, 5);
+  issue_w(0, 0, 0);
+  issue_w(0, 1, 1);
+  int wslot = 0;   // ring slot of the current tap row
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(RTV_LDS const char*)smem;
+  for (int g = 0; g < G; ++g) {
+    const uint32_t hb = lds0 + (g & 1) * HBYTES;
+    sfor<0, 3>([&](auto dyc) {
+      constexpr int dy = decltype(dyc)::value;
+      // W(this tap row) [and, at dy 0, this group's halo] have landed for this wave; younger pieces stay in flight:
+      //   dy 0: W(next row) = 3;  dy 1: W(prev. issue) 3 + halo part 3 = 6;  dy 2: halo 3 + W 3 + halo 2 = 8
+      if (dy == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (dy == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      CH_FENCE();
+      __builtin_amdgcn_s_barrier();   // ... for every wave; everybody is done with the previous tap row (and group)
+      CH_FENCE();
+      // the tap row two ahead -> the ring slot of the previous one; the next group's halo -> the other halo buffer
+      {
+        const int slot2 = wslot == 0 ? 2 : wslot - 1;
+        if (dy == 0) issue_w(g, 2, slot2);
+        else issue_w(g + 1, dy - 1, slot2);
+        if (dy == 0) issue_h(g + 1, 0, 3);
+        if (dy == 1) issue_h(g + 1, 3, 5);
+      }
+      CH_FENCE();
+      const uint32_t wb = lds0 + 2 * HBYTES + wslot * WROW_BYTES;
+      uint32_t aaddr[3][2], baddr[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        baddr[ks] = wb + b_base[ks];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) aaddr[dx][ks] = hb + a_base[dx][ks];
+      }
+      // the six (tap, k-step) chunks of the row, software pipelined two chunks deep: the 5 fragment reads of chunk i + 2 are
+      // issued in front of the 6 MFMAs of chunk i (three register sets, at most 15 LDS reads in flight)
+      u32x4 af[3][2], bf[3][3];   // [set][block]
+      auto load_chunk = [&](auto cic) __attribute__((always_inline)) {
+        constexpr int ci = decltype(cic)::value;
+        constexpr int dx = ci >> 1, ks = ci & 1, set = ci % 3;
+        bf[set][0] = lds_read128<dx * (96 * 64) + 0 * (32 * 64)>(baddr[ks]);
+        bf[set][1] = lds_read128<dx * (96 * 64) + 1 * (32 * 64)>(baddr[ks]);
+        bf[set][2] = lds_read128<dx * (96 * 64) + 2 * (32 * 64)>(baddr[ks]);
+        af[set][0] = lds_read128<(0 + dy) * (HPITCH * 64)>(aaddr[dx][ks]);
+        af[set][1] = lds_read128<(1 + dy) * (HPITCH * 64)>(aaddr[dx][ks]);
+      };
+      load_chunk(IC<0>{});
+      load_chunk(IC<1>{});
+      sfor<0, 6>([&](auto cic) {
+        constexpr int ci = decltype(cic)::value;
+        constexpr int set = ci % 3;
+        if constexpr (ci + 2 < 6) load_chunk(IC<ci + 2>{});
+        lds_wait<(ci + 2 < 6) ? 10 : (ci + 1 < 6 ? 5 : 0)>(bf[set][0], bf[set][1], bf[set][2], af[set][0], af[set][1]);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 3; ++nb) acc[mb][nb] = Mfma32<true>::run(bf[set][nb], af[set][mb], acc[mb][nb]);
+        CH_FENCE();   // keep the chunk's MFMAs in front of the next chunk's wait
+      });
+      CH_FENCE();
+      wslot = wslot == 2 ? 0 : wslot + 1;
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the surplus pieces of the last steps
+  CH_FENCE();
+  __builtin_amdgcn_s_barrier();     // all fragment reads and DMA writes done: LDS becomes the epilogue image
+  CH_FENCE();
+#undef CH_FENCE
+
+  // ---- epilogue: bias (+ residual) through a wave-private 64 x 96 image (rows of 192 bytes), 16 contiguous bytes per lane
+  constexpr int TM = 2, TN = 3, CPR = TN * 4;
+  char* img = smem + wave * (TM * 32 * TN * 64);
+#pragma unroll
+  for (int mi = 0; mi < TM; ++mi) {
+    const int row = mi * 32 + l31;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = n0 + ni * 32 + rq * 8 + gl * 4;
+        float v[4] = {acc[mi][ni][rq * 4 + 0], acc[mi][ni][rq * 4 + 1], acc[mi][ni][rq * 4 + 2], acc[mi][ni][rq * 4 + 3]};
+        if (p.bias) {
+          const u32x2 bb = *(const u32x2*)(p.bias + n);
+          v[0] += f16_to_f32(bb[0] & 0xffff);
+          v[1] += f16_to_f32(bb[0] >> 16);
+          v[2] += f16_to_f32(bb[1] & 0xffff);
+          v[3] += f16_to_f32(bb[1] >> 16);
+        }
+        u32x2 o;
+        o[0] = pack_f16x2(v[0], v[1]);
+        o[1] = pack_f16x2(v[2], v[3]);
+        *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gl)) = o;
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int PASSES = TM * 32 * CPR / 64;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int q = ps * 64 + lane;
+    const int row = q / CPR, c = q - row * CPR;
+    const int y = y0 + 2 * wave + (row >> 5), x = x0 + (row & 31);
+    const int n = n0 + c * 8;
+    u32x4 tv = *(const u32x4*)(img + conv_img_off<TN>(row, c, 0));
+    if (y >= p.H || x >= p.W) continue;
+    const size_t m = ((size_t)t * p.H + y) * p.W + x;
+    if (p.residual) {
+      const u32x4 rr = *(const u32x4*)(p.residual + m * p.res_ld + n);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a0, a1, r0, r1;
+        unpack_f16x2(tv[i], a0, a1);
+        unpack_f16x2(rr[i], r0, r1);
+        tv[i] = pack_f16x2(a0 + r0, a1 + r1);
+      }
+    }
+    *(u32x4*)(p.out + m * p.out_ld + n) = tv;
+  }
+}
+
+static int launch_conv_halo(ConvParams p, hipStream_t stream) {
+  const int tiles_x = (p.W + ch::TW - 1) / ch::TW, tiles_y = (p.H + ch::TH - 1) / ch::TH;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ch::LDS_BYTES);
+    if (e != hipSuccess) return set_error(e, "conv: hipFuncSetAttribute");
+    attr_set = true;
+  }
+  ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 27 * p.Cin);
+  hipLaunchKernelGGL(conv_halo_kernel, dim3(p.T * tiles_y * tiles_x * (p.Cout / 96)), dim3(ch::THREADS), ch::LDS_BYTES, stream, p,
+                     tiles_x, tiles_y);
+  return check_launch("conv_halo");
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   typedef TileCfg<BM, BN, BK, WM, WN> Cfg;
@@ -331,12 +606,22 @@ static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   return check_launch("conv");
 }
 
+static bool g_conv_halo = true;   // rtv_conv_set_halo(0): A/B against conv_igemm_kernel (lab / tests)
+
 int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.M <= 0) return 0;
   if (p.Cin % 32) return set_error(-1, "conv: Cin must be a multiple of 32 (pad channels)");
   if (p.Cout % 8) return set_error(-1, "conv: Cout must be a multiple of 8 (pad filters)");
   if (p.out_ld % 4 || (p.residual && p.res_ld % 4)) return set_error(-1, "conv: channel strides must be multiples of 4");
   if (p.n_split && (p.n_split % 4 || p.Cout != 2 * p.n_split)) return set_error(-1, "conv: bad n_split");
+  // 3x3x3 stride-1 convs at 96 / 192 channels: the halo-tile kernel.  The choice depends on the layer (channels, taps, layout)
+  // only, never on T / H / W: a row-sharded decode must run every layer on the kernel the unsharded one uses (bit parity).
+  const bool halo = g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && !p.ups && p.sy == 1 && p.st == 1 && !p.n_split &&
+                    p.pad_h == 1 && p.pad_w == 1 && p.y_out0 == 0 && p.y_in0 == 0 && p.in_rows == p.inH && p.limH == p.inH &&
+                    p.limW == p.inW && p.Cin % 32 == 0 && p.Cin <= 192 && p.Cout % 96 == 0 && p.Cout <= 192 &&
+                    !((p.out_ld | (p.residual ? p.res_ld : 0)) & 7) && !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15) &&
+                    (size_t)(p.T + 2) * p.inH * p.inW * p.Cin < 0x7fffffffull;
+  if (halo) return launch_conv_halo(p, stream);
   if (p.Cout % 96 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 96, 32, 2, 1>(p, stream);
   if (p.Cout <= 32) return launch_conv_cfg<128, 32, 32, 2, 1>(p, stream);
   return launch_conv_cfg<128, 128, 32, 2, 2>(p, stream);
@@ -345,6 +630,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
 }  // namespace rtv
 
 using namespace rtv;
+
+extern "C" int rtv_conv_set_halo(int on) {
+  g_conv_halo = on != 0;
+  return 0;
+}
 
 /* Row-window variant (spatially sharded decode): the output buffer holds image rows [y_out0, y_out0 + H), the input
  * buffer `in_rows` rows starting at image row y_in0 (input resolution), the image has img_rows rows at OUTPUT resolution.

@@ -1,0 +1,76 @@
+"""A/B of the two 3x3x3 convolution kernels of the VAE decoder (csrc/vae_conv.hip): the halo-tile kernel (round 3) vs the
+implicit-GEMM gather kernel, on the decoder's dominant layers, interleaved rounds, median.  Also checks both against torch's
+fp32 conv3d on the first shape.   usage: python scripts/conv_bench.py [rounds]"""
+import ctypes
+import os
+import statistics
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from realtime_video_amd import _lib  # noqa: E402
+from realtime_video_amd.vae_decoder import pack_conv_weight  # noqa: E402
+
+DEV = "cuda"
+lib = _lib.load()
+lib.rtv_conv_set_halo.argtypes = [ctypes.c_int]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def run(x, wp, b, res, out, T, H, W, Cin, Cout, zeros):
+    _lib.call("rtv_conv_cl", p(x), p(wp), p(b), p(res), Cout, p(out), Cout, T, H, W, Cin, Cout, 3, 3, 3, 0, 0, p(zeros),
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+def timed(fn, iters=5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+shapes = [(96, 96, 4, 480, 832), (192, 192, 4, 240, 416), (96, 96, 4, 60, 832), (192, 96, 4, 240, 416), (96, 192, 2, 240, 416)]
+zeros = torch.zeros(64, dtype=torch.float16, device=DEV)
+with torch.backends.cudnn.flags(enabled=False):
+    for si, (Cin, Cout, T, H, W) in enumerate(shapes):
+        g = torch.Generator().manual_seed(5)
+        x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.5).half().to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
+        b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
+        res = torch.randn(T, H, W, Cout, generator=g).half().to(DEV)
+        wp = pack_conv_weight(w).to(DEV)
+        outs = {}
+        for halo in (1, 0):
+            lib.rtv_conv_set_halo(halo)
+            outs[halo] = torch.empty(T, H, W, Cout, dtype=torch.float16, device=DEV)
+            run(x, wp, b, res, outs[halo], T, H, W, Cin, Cout, zeros)
+        torch.cuda.synchronize()
+        line = f"{Cin:3d}->{Cout:3d} T{T} {H}x{W}: "
+        if si == 0 or H * W <= 240 * 416:
+            xin = x.permute(3, 0, 1, 2).unsqueeze(0).float()
+            ref = F.conv3d(F.pad(xin, (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+            ref = ref.half().float() + res.float()
+            for halo in (1, 0):
+                d = (outs[halo].float() - ref).abs().max().item()
+                line += f"max|{'halo' if halo else 'gather'} - fp32| {d:.2e}  "
+        line += f"kernels differ in {(outs[1] != outs[0]).float().mean().item() * 100:.3f} % of the outputs; "
+        t = {1: [], 0: []}
+        for _ in range(rounds):
+            for halo in (1, 0):
+                lib.rtv_conv_set_halo(halo)
+                t[halo].append(timed(lambda: run(x, wp, b, res, outs[halo], T, H, W, Cin, Cout, zeros)))
+        flop = 2.0 * T * H * W * Cout * 27 * Cin
+        for halo in (1, 0):
+            ms = statistics.median(t[halo])
+            line += f" {'halo' if halo else 'gather'} {ms * 1e3:7.1f} us {flop / ms / 1e9:6.0f} TF/s"
+        print(line, flush=True)
+lib.rtv_conv_set_halo(1)
