@@ -312,6 +312,10 @@ int rtv_gemm_fp8(const void* A, int lda, const void* W, int ldw, const float* a_
  *   n_split>0 scatters output channel halves to frames 2t, 2t+1 (decoder time_conv).
  *   Cin % 32 == 0, Cout % 8 == 0; `zeros` = >=16 zero bytes. */
 enum { RTV_CONV_NONE = 0, RTV_CONV_UPSAMPLE2X = 1, RTV_CONV_DOWN2X = 2, RTV_CONV_TIME_DOWN2X = 3 };
+/* OR-ed into `resample`: run a 3x3x3 stride-1 convolution on the implicit-GEMM gather kernel instead of the halo-tile kernel
+ * (the VAE orchestrators set it for the latent-resolution layers: a 60 x 104 image is 16 halo tiles, too few for 256 CUs).
+ * A property of the LAYER, never of the launch size: row-sharded and unsharded decodes must pick the same kernel per layer. */
+enum { RTV_CONV_GATHER = 16 };
 int rtv_conv_cl(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
                 void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                 int resample, int n_split, const void* zeros, rtv_stream_t stream);

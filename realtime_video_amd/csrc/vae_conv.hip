@@ -41,6 +41,7 @@ struct ConvParams {
   int y_out0, y_in0; // row windows (spatially sharded decode): output row py is image row y_out0 + py, input buffer row 0
                      // is image row y_in0 (in input resolution); limH is then the IMAGE height
   int in_rows;       // rows held by the input buffer
+  int gather;       // 1: keep a 3x3x3 stride-1 conv on the gather kernel (RTV_CONV_GATHER)
   int n_split;      // >0: output channel n -> frame 2t + n / n_split, channel n % n_split
   int M;            // T*H*W
   int tiles_m, tiles_n;
@@ -614,11 +615,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.Cout % 8) return set_error(-1, "conv: Cout must be a multiple of 8 (pad filters)");
   if (p.out_ld % 4 || (p.residual && p.res_ld % 4)) return set_error(-1, "conv: channel strides must be multiples of 4");
   if (p.n_split && (p.n_split % 4 || p.Cout != 2 * p.n_split)) return set_error(-1, "conv: bad n_split");
-  // 3x3x3 stride-1 convs at 96 / 192 channels: the halo-tile kernel.  The choice depends on the layer (channels, taps, layout)
+  // 3x3x3 stride-1 convs at 96 / 192 / 384 channels: the halo-tile kernel (unless the caller marks the layer RTV_CONV_GATHER).  The choice depends on the layer (channels, taps, layout)
   // only, never on T / H / W: a row-sharded decode must run every layer on the kernel the unsharded one uses (bit parity).
-  const bool halo = g_conv_halo && p.kt == 3 && p.kh == 3 && p.kw == 3 && !p.ups && p.sy == 1 && p.st == 1 && !p.n_split &&
+  const bool halo = g_conv_halo && !p.gather && p.kt == 3 && p.kh == 3 && p.kw == 3 && !p.ups && p.sy == 1 && p.st == 1 && !p.n_split &&
                     p.pad_h == 1 && p.pad_w == 1 && p.y_out0 == 0 && p.y_in0 == 0 && p.in_rows == p.inH && p.limH == p.inH &&
-                    p.limW == p.inW && p.Cin % 32 == 0 && p.Cin <= 192 && p.Cout % 96 == 0 && p.Cout <= 192 &&
+                    p.limW == p.inW && p.Cin % 32 == 0 && p.Cin <= 384 && p.Cout % 96 == 0 && p.Cout <= 384 &&
                     !((p.out_ld | (p.residual ? p.res_ld : 0)) & 7) && !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15) &&
                     (size_t)(p.T + 2) * p.inH * p.inW * p.Cin < 0x7fffffffull;
   if (halo) return launch_conv_halo(p, stream);
@@ -657,6 +658,8 @@ extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, 
                                int resample, int n_split, const void* zeros, int y_out0, int y_in0, int in_rows,
                                int img_rows, rtv_stream_t stream) {
   if (!in || !w || !out || !zeros) return set_error(-1, "conv: null pointer");
+  const int gather = (resample & RTV_CONV_GATHER) ? 1 : 0;
+  resample &= ~RTV_CONV_GATHER;
   if ((kt != 1 && kt != 3) || (kh != 1 && kh != 3) || kh != kw) return set_error(-1, "conv: kernel must be 1 or 3 per axis");
   if (resample < 0 || resample > 3) return set_error(-1, "conv: resample must be 0..3");
   const int ups = resample == RTV_CONV_UPSAMPLE2X;
@@ -703,6 +706,7 @@ extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, 
     p.inH = in_rows;      // slice stride of the input buffer
     p.limH = img_rows;
   }
+  p.gather = gather;
   p.Cin = Cin;
   p.Cout = Cout;
   p.kt = kt;

@@ -386,8 +386,10 @@ struct Ctx {
 static int cached_conv3(Ctx& c, int ci, int T, int H, int W, int Cin, const rtv_vae_conv& cw, int Cout,
                         const void* residual, void* out, int out_ld) {
   uint16_t* buf = c.cat(ci);
-  RTV_TRY(rtv_conv_cl(buf, cw.w, cw.b, residual, Cout, out, out_ld, T, H, W, Cin, Cout, 3, 3, 3, 0, 0, c.zeros(),
-                      c.stream));
+  // latent-resolution layers (mid block, first stage: W == the latent width in sharded and unsharded decodes alike) stay on
+  // the gather kernel - 16 halo tiles per frame cannot fill the chip (scripts/conv_bench.py: 315 vs 399 TF/s at 60 x 104)
+  RTV_TRY(rtv_conv_cl(buf, cw.w, cw.b, residual, Cout, out, out_ld, T, H, W, Cin, Cout, 3, 3, 3,
+                      W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE, 0, c.zeros(), c.stream));
   const size_t slice = (size_t)H * W * Cin * 2;
   char* b = (char*)buf;
   if (T == 1) {

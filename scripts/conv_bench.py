@@ -38,7 +38,8 @@ def timed(fn, iters=5):
     return e0.elapsed_time(e1) / iters
 
 
-shapes = [(96, 96, 4, 480, 832), (192, 192, 4, 240, 416), (96, 96, 4, 60, 832), (192, 96, 4, 240, 416), (96, 192, 2, 240, 416)]
+shapes = [(96, 96, 4, 480, 832), (192, 192, 4, 240, 416), (96, 96, 4, 60, 832), (192, 96, 4, 240, 416), (96, 192, 2, 240, 416),
+          (384, 384, 4, 120, 208), (384, 384, 2, 120, 208), (384, 384, 1, 60, 104), (192, 384, 4, 120, 208), (384, 384, 4, 15, 208)]
 zeros = torch.zeros(64, dtype=torch.float16, device=DEV)
 with torch.backends.cudnn.flags(enabled=False):
     for si, (Cin, Cout, T, H, W) in enumerate(shapes):

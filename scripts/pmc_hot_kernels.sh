@@ -8,7 +8,7 @@ RAW=/tmp/pmc_hot
 OUT=$R/gpurun_out/pmc_hot
 rm -rf $RAW; mkdir -p $RAW $OUT
 cd /tmp
-for k in gemm attn conv layernorm rope; do
+for k in ${KERNELS:-gemm attn conv layernorm rope}; do
   i=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS" \

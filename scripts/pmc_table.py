@@ -9,8 +9,8 @@ import sqlite3
 import sys
 
 root = sys.argv[1]
-ROCM_KERNELS = {"gemm": "gemm8_kernel", "attn": "attn_fwd_kernel", "conv": "conv_igemm_kernel", "layernorm": "layernorm_modulate_kernel",
-                "rope": "qk_norm_rope_cache_kernel"}
+ROCM_KERNELS = {"gemm": "gemm8_kernel", "attn": "attn_fwd%_kernel", "conv": "conv_%_kernel", "layernorm": "layernorm_modulate_kernel",
+                "rope": "qk_norm_rope_cache_kernel"}   # SQL LIKE patterns (conv: conv_halo_kernel / conv_igemm_kernel, attn: lockstep / four-phase)
 
 
 def counters(k):
