@@ -51,7 +51,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 __device__ unsigned long long* g_timeline = nullptr;   // [grid][4]: realtime start, after K loop, end, (seg << 32 | tile)
 #endif
 
-template <bool F16>
+template <bool F16, bool SKIP_IDLE>
 __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
 #ifdef RTV_GEMM_TIMELINE
@@ -157,6 +157,9 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 
   // MFMA segment: 16 MFMA on the 64 x 64 half (mq; n0, n1) with 4 DMA pieces between them (halves h0, h0 + 1 of K-tile
   // st_kt): an LDS-DMA costs 60-180 issue cycles inside an LDS segment but ~10 behind an MFMA.
+  // A wave whose 128 rows all lie beyond M (M = 4680: waves 4-7 of the last row of tiles) has nothing to multiply: it keeps
+  // its barriers and its DMA duty (the pieces it stages are other waves' operands) and skips fragment reads and MFMAs.
+  const bool idle_rows = SKIP_IDLE && m0 + wr * 128 >= p.M;   // wave-uniform
   auto mma_half = [&](int mq, int st_kt, int st_a3, int h0, auto chk) {
     __builtin_amdgcn_s_setprio(1);
     int n = 0;
@@ -214,9 +217,30 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     G8_BARRIER();
     a3 = a3 == 2 ? 0 : a3 + 1;
   };
+  // The same K-tile for a wave with nothing to multiply: barriers, DMA pieces and counted waits at the same points, no
+  // fragment reads, no MFMAs.  (A separate loop: with the test inside k_tile the six scalar branches per K-tile cost every
+  // tile 3-4 %, profiles/r03_gemm_idle_waves_ab.log.)
+  auto idle_tile = [&](const int kt) {
+    const int a3n = a3 == 0 ? 2 : a3 - 1;
+    G8_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece(kt + 2, a3n, i >> 1, i & 1, std::true_type{});
+    G8_BARRIER();
+    if (kt + 2 < kt_end) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G8_BARRIER();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage_piece(kt + 2, a3n, 2 + (i >> 1), i & 1, std::true_type{});
+    G8_BARRIER();
+    a3 = a3 == 2 ? 0 : a3 + 1;
+  };
   int kt = kt_begin;
-  for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});   // steady state: K-tile kt + 2 exists
-  for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});        // last two K-tiles
+  if (idle_rows) {
+    for (; kt < kt_end; ++kt) idle_tile(kt);
+  } else {
+    for (; kt + 2 < kt_end; ++kt) k_tile(kt, std::false_type{});   // steady state: K-tile kt + 2 exists
+    for (; kt < kt_end; ++kt) k_tile(kt, std::true_type{});        // last two K-tiles
+  }
   if (wr == 0) G8_BARRIER();  // group 0 closes the stagger: every LDS read and DMA of the loop is retired
 
   // ---- split-K fix-up: publish the partial tile, last arriver reduces (placement-independent agent-scope
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 // one K-tile further ahead: MFMA(t) stages K-tile t + 2 + group (6 pieces per wave) into buffer (t + 2 + group) % 3, then
 // waits with vmcnt(6) - everything but the pieces it has just issued - so each piece is in flight for two to three
 // intervals before the counted wait retires it, one barrier before its first reader.
+static bool g_gemm8_skip_idle = true;   // rtv_gemm_set_skip_idle(0): A/B (lab)
 namespace g8m {
 constexpr int BM = 128, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
@@ -494,6 +519,11 @@ extern "C" int rtv_gemm_debug_timeline(unsigned long long* buf) {
 }
 #endif
 
+extern "C" int rtv_gemm_set_skip_idle(int on) {
+  rtv::g_gemm8_skip_idle = on != 0;
+  return 0;
+}
+
 extern "C" size_t rtv_gemm_workspace_bytes(void) {
   return (size_t)SPLIT_MAX_UNITS * SPLIT_SLAB_FLOATS * 4 + (size_t)SPLIT_MAX_UNITS * 4 + 256;
 }
@@ -553,11 +583,11 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
   return 0;
 }
 
-template <bool F16>
+template <bool F16, bool SKIP_IDLE>
 static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   p.tiles_m = (p.M + g8::BM - 1) / g8::BM;
   p.tiles_n = (p.N + g8::BN - 1) / g8::BN;
-  auto kern = gemm8_kernel<F16>;
+  auto kern = gemm8_kernel<F16, SKIP_IDLE>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES);
@@ -601,7 +631,10 @@ int launch_gemm8(const GemmParams& p, bool f16, bool split, hipStream_t stream) 
   // the buffer descriptors address the operands with 32-bit byte offsets
   if ((size_t)p.M * p.lda * 2 > 0x7fffffffull || (size_t)p.N * p.ldw * 2 > 0x7fffffffull)
     return set_error(-1, "gemm8: operand larger than 2 GiB");
-  return f16 ? launch_gemm8_t<true>(p, split, stream) : launch_gemm8_t<false>(p, split, stream);
+  // the idle-wave build only where it has something to skip: the last row of tiles holds <= 128 real rows
+  const int last_rows = p.M - (p.M - 1) / g8::BM * g8::BM;
+  if (g_gemm8_skip_idle && !f16 && last_rows <= 128) return launch_gemm8_t<false, true>(p, split, stream);
+  return f16 ? launch_gemm8_t<true, false>(p, split, stream) : launch_gemm8_t<false, false>(p, split, stream);
 }
 
 }  // namespace rtv

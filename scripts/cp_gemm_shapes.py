@@ -33,7 +33,15 @@ for m in [int(x) for x in os.environ.get("CP_M", "4680,2340,1170,585").split(","
         w = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
         b = torch.randn(n, device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-        fns = {f"cfg{c}": (lambda c: (lambda: ops.gemm(a, w, bias=b, out=out, tile_cfg=c)))(c) for c in cfgs}
+        # cfg >= 1000: the same tile config with the idle-wave skipping of gemm8 switched off (A/B)
+        lib = __import__("realtime_video_amd._lib", fromlist=["load"]).load()
+
+        def variant(c):
+            def run():
+                lib.rtv_gemm_set_skip_idle(0 if c >= 1000 else 1)
+                ops.gemm(a, w, bias=b, out=out, tile_cfg=c % 1000)
+            return run
+        fns = {f"cfg{c}": variant(c) for c in cfgs}
         if os.environ.get("CP_TORCH", "1") == "1":
             fns["hipBLASLt"] = lambda: torch.nn.functional.linear(a, w, b)
         for f in fns.values():
