@@ -36,6 +36,7 @@ struct AttnParams {
   // window is cache row v for v < n0 and row v + delta for v >= n0 (rows relative to k / v); n0 == Lkv: one segment.
   int n0, delta;
   int off0;   // four-phase kernel only: keys v < n0 are cache rows v + off0 (its k / v point at the lowest row of the window)
+  int skip_idle;  // four-phase kernel only: waves whose 32 query rows all lie beyond Lq run the idle loop (A/B switch)
 };
 
 constexpr int ATT_D = 128;
@@ -600,6 +601,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
   __syncthreads();
   if (grp) PP_BARRIER();   // the stagger
 
+  // A wave whose 32 query rows all lie beyond Lq (Lq = 4680: waves 3-7 of the 19th query tile of every head) has nothing to
+  // compute: it keeps its four barriers per tile and its K / V DMA duty (the tiles are shared) and skips the fragment
+  // reads, both matrix phases and the softmax - a separate loop, the working waves' loop carries no test for it.
+  const bool idle_rows = p.skip_idle && q0 + wave * ATT_QW >= p.Lq;   // wave-uniform
+  if (idle_rows) {
+    for (int j = 0; j < ntiles; ++j) {
+      stage_k(j + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      PP_BARRIER();
+      PP_BARRIER();
+      stage_v(j + 2);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      PP_BARRIER();
+      PP_BARRIER();
+    }
+    if (!grp) PP_BARRIER();
+    return;
+  }
   for (int j = 0; j < ntiles; ++j) {
     const int slot_off = (j % ATT_NB) * ATT_TILE_BYTES;
     // ---------------- LK
@@ -753,6 +772,12 @@ extern "C" int rtv_attn_debug_trace(unsigned* buf) {
 static int g_attn_waves = 0;     // 0 = by grid size
 static bool g_attn_lockstep = false;  // 256-row launches on the lockstep kernel only (A/B runs, tests)
 static bool g_attn_force_pp = false;  // ... on the four-phase kernel whatever the window length
+static bool g_attn_skip_idle = true;  // rtv_attn_set_skip_idle(0): A/B of the idle-wave loop (lab)
+
+extern "C" int rtv_attn_set_skip_idle(int on) {
+  g_attn_skip_idle = on != 0;
+  return 0;
+}
 
 extern "C" int rtv_attn_set_waves(int waves) {
   if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82)
@@ -838,6 +863,7 @@ extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, voi
   // Four-phase kernel: its DMA addresses K / V rows with non-negative 32-bit byte offsets from a buffer base, so the base is
   // the lowest row of the window (the second range of a ring window lies BELOW the first one).
   p.off0 = 0;
+  p.skip_idle = g_attn_skip_idle ? 1 : 0;
   const int base_shift = (Lkv1 > 0 && seg1_row < 0) ? seg1_row : 0;
   const int64_t top0 = (int64_t)p.n0 - base_shift, top1 = (int64_t)Lkv + p.delta - base_shift;
   const int64_t rs_max = k_row_stride > v_row_stride ? k_row_stride : v_row_stride;
