@@ -842,7 +842,10 @@ extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, voi
   // waves): 4680 rows x 20 heads 0.90 / 0.88, x 10 heads (190 workgroups) 0.46 / 0.51, x 5 heads (95) 0.40 / 0.32,
   // 585 rows x 40 heads (120) 0.40 / 0.34.
   int waves = g_attn_waves;
-  if (waves == 0) waves = (int64_t)B * H * ((Lq + 255) / 256) < 160 ? 4 : 8;
+  // 128-row / 4-wave workgroups (two per CU) when the 256-row grid cannot fill the chip, and for short key windows (the
+  // text cross-attention, 512 keys = 8 tiles): a workgroup is then mostly prologue and epilogue, which two co-resident
+  // workgroups overlap (scripts/cross_attn_ab.py: 74.9 vs 79.0 us at 4680 x 512 x 40 heads; bit-identical)
+  if (waves == 0) waves = ((int64_t)B * H * ((Lq + 255) / 256) < 160 || Lkv <= 512) ? 4 : 8;
   const int qt_rows = ATT_QW * waves;
   p.n_qtiles = (Lq + qt_rows - 1) / qt_rows;
   const int lds = 4 * ATT_TILE_BYTES;
