@@ -234,6 +234,9 @@ typedef struct rtv_dit_step {
   int row_begin, row_count; /* token rows owned by this rank (context parallel); 0,0 = all M rows */
   int ring_lo, ring_size, ring_shift; /* rolling cache kept as a ring: cache_row0 / kv_lo / kv_hi are LOGICAL rows; logical row
                                r >= ring_lo lives at ring_lo + (r - ring_lo + ring_shift) % ring_size (ring_size 0: no ring) */
+  int kv_only;              /* 1: the caller only wants the KV cache filled and discards the output (the session's KV-recompute
+                               pass, release_server.py:611-632): everything behind the LAST layer's cache write - its q projection,
+                               attention, o-projection, cross-attention, FFN, the head - is skipped, `out` is left untouched */
 } rtv_dit_step;
 
 size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw);

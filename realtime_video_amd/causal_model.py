@@ -60,7 +60,8 @@ class _Step(ctypes.Structure):
                 ("kv_lo", ctypes.c_int), ("kv_hi", ctypes.c_int), ("start_frame", ctypes.c_int),
                 ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int),
                 ("row_begin", ctypes.c_int), ("row_count", ctypes.c_int),
-                ("ring_lo", ctypes.c_int), ("ring_size", ctypes.c_int), ("ring_shift", ctypes.c_int)]
+                ("ring_lo", ctypes.c_int), ("ring_size", ctypes.c_int), ("ring_shift", ctypes.c_int),
+                ("kv_only", ctypes.c_int)]
 
 
 _lib.EXTRA_SIGNATURES["rtv_dit_forward"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step),
@@ -444,6 +445,10 @@ class CausalWanModel:
             ctx[:cu.shape[0]] = cu.to(torch.bfloat16)
         cp = self.context_parallel
         use_cp = cp is not None and cp.world > 1
+        # `kv_cache_only` (set by the session around its KV-recompute pass, whose output the reference discards as well,
+        # release_server.py:611-632): the forward stops behind the last layer's K / V cache write; the returned tensor is zeros
+        # (not while the cross-attention caches are still to be filled: the last layer's text K / V are computed in its rest phase)
+        kv_only = bool(getattr(self, "kv_cache_only", False)) and not need_cross
         row0, lo, hi, start_frame, causal_block, (ring_lo, ring_size, ring_shift), commit = \
             self._cache_window(kv_cache, M, current_start, fs, ring=not use_cp)
         L = self.num_layers
@@ -462,7 +467,7 @@ class CausalWanModel:
         kv_keep, kv = ptr_array([c["v"] for c in kv_cache])
         ck_keep, ck = ptr_array([c["k"] for c in crossattn_cache])
         cv_keep, cv = ptr_array([c["v"] for c in crossattn_cache])
-        out = torch.empty((self.out_dim, F, Hh, Ww), dtype=torch.bfloat16, device=u.device)
+        out = (torch.zeros if kv_only else torch.empty)((self.out_dim, F, Hh, Ww), dtype=torch.bfloat16, device=u.device)
         stream = c_vp(torch.cuda.current_stream().cuda_stream)
         cfg_p, w_p = ctypes.byref(self._cfg), ctypes.byref(self._w)
 
@@ -472,7 +477,7 @@ class CausalWanModel:
             st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
                        F, gh, gw, kk, kv, rs, ck, cv, int(need_cross), row0, lo, hi,
                        start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1],
-                       ring_lo, ring_size, ring_shift)
+                       ring_lo, ring_size, ring_shift, int(kv_only))
             return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
 
         if self.gemm_tile_cfg in (0, 5):
@@ -485,7 +490,7 @@ class CausalWanModel:
                 # the ~530 launches of one forward replayed as ONE hipGraph.  Everything the launch sequence
                 # depends on is part of the key (steady state has two entries: the recompute pass and the denoise step);
                 # the latent / timestep / output live in static buffers.  The first sighting of a key runs eagerly.
-                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, ring_lo, ring_size, ring_shift,
+                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, ring_lo, ring_size, ring_shift, kv_only,
                              int(self.gemm_tile_cfg), rs, self._weights_version,
                              kv_cache[0]["k"].data_ptr(), kv_cache[-1]["v"].data_ptr(), crossattn_cache[0]["k"].data_ptr())
                 ent = self._graphs.get(graph_key)
@@ -549,16 +554,26 @@ class CausalWanModel:
             #   heads exchange: [LN | Q]   -> all-to-all(q) (async) -> [K,V] -> all-to-all(k|v) (async) -> wait both -> attention
             null = c_vp(0)
             for l in range(L):
+                last_kv_only = kv_only and l == L - 1      # only the K / V rows of the last layer are still needed
                 if not heads:
                     for st, wsa in parts:
                         _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, 0, null, null, *wsa)
                     pend = cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
+                    if last_kv_only:
+                        pend.wait()
+                        break
                     for st, wsa in parts:
                         _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_Q, 0, null, null, *wsa)
                     pend.wait()
                     for st, wsa in parts:
                         _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
                     continue
+                if last_kv_only:
+                    for (st, wsa), (_, b) in zip(parts, bufs):
+                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, W, null,
+                                  c_vp(b["kv_send"].data_ptr()), *wsa)
+                    cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                    break
                 for (st, wsa), (_, b) in zip(parts, bufs):
                     _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_Q, W,
                               c_vp(b["q_send"].data_ptr()), null, *wsa)
@@ -575,11 +590,12 @@ class CausalWanModel:
                 cp.exchange_o(bufs)
                 for (st, wsa), (_, b) in zip(parts, bufs):
                     _lib.call("rtv_dit_layer_rest_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["o_recv"].data_ptr()), *wsa)
-            hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
-            for st, wsa in parts:
-                _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)
-            cp.all_gather_rows_(hrow)
-            _lib.call("rtv_dit_finish", cfg_p, ctypes.byref(parts[0][0]), c_vp(hrow.data_ptr()), stream)
+            if not kv_only:
+                hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
+                for st, wsa in parts:
+                    _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)
+                cp.all_gather_rows_(hrow)
+                _lib.call("rtv_dit_finish", cfg_p, ctypes.byref(parts[0][0]), c_vp(hrow.data_ptr()), stream)
         if need_cross:
             for c in crossattn_cache:
                 c["is_init"] = True

@@ -453,6 +453,8 @@ extern "C" int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights*
     return set_error(-1, "dit_forward: sharded row ranges need the phase API (rtv_dit_begin/layer_qkv/layer_rest/head/finish)");
   RTV_TRY(dit_begin(c));
   for (int l = 0; l < c.L; ++l) {
+    if (st->kv_only && l == c.L - 1)   // nothing downstream of the last layer's K / V rows is consumed
+      return dit_layer_proj(c, l, RTV_PROJ_LN | RTV_PROJ_KV, 0, nullptr, nullptr);
     RTV_TRY(dit_layer_qkv(c, l));
     RTV_TRY(dit_layer_rest(c, l));
   }

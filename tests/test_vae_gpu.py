@@ -57,6 +57,36 @@ def test_causal_conv3d_with_cache_concat(Cin, Cout, T, H, W):
     assert max_abs(out, ref) <= 1e-2 and rel_l2(out, ref) <= 2e-3
 
 
+@pytest.mark.parametrize("Cin,Cout,T,H,W", [(96, 96, 2, 33, 70),      # ragged on both axes: 3 x 3 tiles, partial last row / column
+                                             (32, 96, 1, 16, 32),       # the encoder's first conv (3 -> 32 padded channels): one chunk per slice
+                                             (192, 384, 3, 17, 31),     # four filter tiles per pixel tile, a single ragged tile
+                                             (384, 192, 1, 48, 64),     # twelve channel chunks per time slice
+                                             (96, 192, 4, 5, 100)])     # fewer rows than a tile, four column tiles
+def test_halo_conv_kernel_edges_and_gather_flag(Cin, Cout, T, H, W):
+    """The halo-tile kernel (conv_halo_kernel: 16 x 32 pixel tiles, halo staged once per time slice and channel chunk) on
+    ragged image sizes, every channel configuration it is dispatched for, with and without bias / residual - against torch's
+    fp32 conv3d and against the gather kernel selected by RTV_CONV_GATHER (same math, another K order: equal up to fp32
+    association, i.e. isolated one-ulp fp16 differences).  Repeated launches must be bit-identical (race screen of the
+    DMA / barrier schedule)."""
+    RTV_CONV_GATHER = 16
+    g = torch.Generator().manual_seed(Cin + Cout + T + H)
+    x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.7).half().to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
+    res = torch.randn(T, H, W, Cout, generator=g).half().to(DEV)
+    xin = x.permute(3, 0, 1, 2).unsqueeze(0).float()
+    conv = F.conv3d(F.pad(xin, (1, 1, 1, 1, 0, 0)), w.float())[0].permute(1, 2, 3, 0)
+    for bias, residual in ((b, res), (None, None), (b, None)):
+        ref = conv + (bias.float() if bias is not None else 0.0)
+        ref = ref.half().float() + (residual.float() if residual is not None else 0.0)
+        outs = [_conv_cl(x, w, bias, T, H, W, 3, 3, 3, residual=residual) for _ in range(3)]
+        assert max_abs(outs[0], ref) <= 1e-2 and rel_l2(outs[0], ref) <= 2e-3
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        gather = _conv_cl(x, w, bias, T, H, W, 3, 3, 3, ups=RTV_CONV_GATHER, residual=residual)
+        assert max_abs(gather, ref) <= 1e-2
+        assert float((gather != outs[0]).float().mean()) <= 5e-3 and max_abs(gather, outs[0]) <= 4e-3
+
+
 def test_upsample_conv2d_and_time_conv():
     g = torch.Generator().manual_seed(3)
     T, H, W, C = 2, 6, 10, 192
