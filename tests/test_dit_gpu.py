@@ -656,6 +656,47 @@ def test_fp8_context_parallel_matches_row_sharded_fp8_oracle(exchange):
         assert 0 < rel_l2(sharded, whole) <= 5e-2
 
 
+@pytest.mark.parametrize("cp_world", [0, 2])
+def test_kv_cache_only_forward_fills_the_same_cache(cp_world):
+    """`model.kv_cache_only` (what the session sets around its KV-recompute pass, whose output the reference discards,
+    release_server.py:611-632): the forward stops behind the last layer's cache write - the KV caches of EVERY layer are bit-identical
+    to those of the full recompute forward, the indices advance the same way, the returned tensor is zeros; with the
+    cross-attention caches still uninitialised the switch is ignored (the last layer's text K / V are computed in its rest
+    phase).  Also through the context-parallel phase API (two shards in lockstep)."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.parallel import SimulatedContextParallel
+    cfg, text_dim, tiny_inputs = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    lat, ctx = tiny_inputs()
+    t, t0 = torch.ones([1, 3], dtype=torch.int64) * 700, torch.zeros([1, 3], dtype=torch.int64)
+    res = {}
+    for only in (False, True):
+        model, wr = _build(cfg, text_dim, w)
+        if cp_world:
+            model.context_parallel = SimulatedContextParallel(cp_world, "heads")
+        kv, ca = _caches(cfg, 9360)
+        cond = {"prompt_embeds": [ctx.to(DEV)]}
+        model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560, num_frame_per_block=3)
+        model.kv_cache_only = only
+        first, _ = wr(lat[2].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680)    # cross caches uninitialised: full forward
+        assert all(c["is_init"] for c in ca)
+        for c in kv:
+            c["global_end_index"] = c["local_end_index"] = 0
+        rc, _ = wr(lat[1].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680)        # the switch takes effect here
+        model.kv_cache_only = False
+        model.block_mask = None
+        nxt, _ = wr(lat[3].to(DEV), cond, t.to(DEV), kv, ca, current_start=4680)          # a denoise step on the recomputed cache
+        res[only] = (first, rc, nxt, [c["k"].clone() for c in kv], [c["v"].clone() for c in kv],
+                     [(int(c["global_end_index"]), int(c["local_end_index"])) for c in kv])
+    full, part = res[False], res[True]
+    assert torch.equal(full[0], part[0]) and float(full[0].float().abs().max()) > 0     # ignored while the text caches fill
+    assert float(part[1].float().abs().max()) == 0 and float(full[1].float().abs().max()) > 0
+    assert torch.equal(full[2], part[2])                                                 # the next step sees the same cache
+    for a, b in zip(full[3] + full[4], part[3] + part[4]):
+        assert torch.equal(a, b)
+    assert full[5] == part[5]
+
+
 def test_hip_graph_replay_equals_eager():
     """with use_hip_graphs the recompute pass and the denoise step of the steady state are captured into
     hipGraphs (second sighting) and replayed afterwards; four blocks must equal the eager session bit for bit."""

@@ -471,6 +471,36 @@ def test_gemm_full_14b_shapes(ops, name, N, K, act):
         assert rel_l2(lin, (ref.float() - b.float())) <= 1e-2
 
 
+def test_idle_wave_loops_change_nothing_but_the_time(ops):
+    """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
+    only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
+    with and without the split-K tail, for row counts that leave one to seven idle waves."""
+    from realtime_video_amd import _lib
+    lib = _lib.load()
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    try:
+        for M, N, K, cfg in ((4680, 5120, 1024, 5), (4680, 15360, 512, 4), (585, 2560, 640, 5), (300, 1536, 256, 4), (3, 512, 192, 4)):
+            a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+            outs = []
+            for on in (1, 0):
+                lib.rtv_gemm_set_skip_idle(on)
+                outs.append(ops.gemm(a, w, bias=b, act=1, tile_cfg=cfg).clone())
+            assert torch.equal(outs[0], outs[1]), (M, N, K, cfg)
+        for Lq, Lkv, H in ((4680, 2048, 4), (300, 1500, 2), (33, 1100, 3), (1000, 1024, 1)):
+            q, k, v = _randn(1, Lq, H, 128, seed=4), _randn(1, Lkv, H, 128, seed=5), _randn(1, Lkv, H, 128, seed=6)
+            outs = []
+            ops.attn_set_waves(82)                      # the four-phase kernel whatever the grid size
+            for on in (1, 0):
+                lib.rtv_attn_set_skip_idle(on)
+                outs.append(ops.attn_fwd(q, k, v).clone())
+            assert torch.equal(outs[0], outs[1]), (Lq, Lkv, H)
+            assert max_abs(outs[0], _attn_ref(q, k, v)) <= 2.5e-2
+    finally:
+        lib.rtv_gemm_set_skip_idle(1)
+        lib.rtv_attn_set_skip_idle(1)
+        ops.attn_set_waves(0)
+
+
 def test_attention_full_size_properties(ops):
     """Self-attention at the benchmarked size (4680 queries x 9360 cached keys x 40 heads, the 14B denoise step): (1) against
     the fp32 definition on a sample of heads; (2) invariance under a permutation of the keys (softmax-weighted sums do not
