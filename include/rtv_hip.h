@@ -70,6 +70,18 @@ int rtv_attn_fwd_win(const void* q, const void* k, const void* v, void* o,
                      int64_t v_batch_stride, int64_t v_row_stride,
                      int64_t o_batch_stride, int64_t o_row_stride,
                      float scale, int causal_block, int q_offset, int dtype, rtv_stream_t stream);
+/* Dense attention in which key `dup_key` stands for `dup_count` IDENTICAL keys: softmax attention over a window that holds n
+ * copies of one (k, v) row equals attention over one copy whose score gets + log(n).  This is the text cross-attention of
+ * model.py:171-228 without its redundant work: the prompt embedding is zero-padded to 512 rows (utils/wan_wrapper.py:52-53), the
+ * text MLP, the k / v projections and the k-norm map every padding row to the same K and V row, so the window is the real rows
+ * plus ONE padding row counted 512 - n_real times (mathematically identical; fp32 summation order differs). */
+int rtv_attn_fwd_dup(const void* q, const void* k, const void* v, void* o,
+                     int B, int Lq, int Lkv, int H, int D,
+                     int64_t q_batch_stride, int64_t q_row_stride,
+                     int64_t k_batch_stride, int64_t k_row_stride,
+                     int64_t v_batch_stride, int64_t v_row_stride,
+                     int64_t o_batch_stride, int64_t o_row_stride,
+                     float scale, int dup_key, int dup_count, int dtype, rtv_stream_t stream);
 /* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
  * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  256-row launches over >= 1024 keys run the
  * four-phase kernel (K/V by LDS DMA, fragments read a phase ahead of their MFMAs, the two wave groups one phase apart),
@@ -234,6 +246,10 @@ typedef struct rtv_dit_step {
   int row_begin, row_count; /* token rows owned by this rank (context parallel); 0,0 = all M rows */
   int ring_lo, ring_size, ring_shift; /* rolling cache kept as a ring: cache_row0 / kv_lo / kv_hi are LOGICAL rows; logical row
                                r >= ring_lo lives at ring_lo + (r - ring_lo + ring_shift) % ring_size (ring_size 0: no ring) */
+  int text_rows;            /* > 0: rows [text_rows, text_len) of the prompt embedding behind the cross-attention caches are all
+                               zero padding, i.e. their cached K / V rows are identical: the cross-attention attends rows
+                               [0, text_rows] with the last one counted text_len - text_rows times (rtv_attn_fwd_dup).
+                               0: attend all text_len rows */
   int kv_only;              /* 1: the caller only wants the KV cache filled and discards the output (the session's KV-recompute
                                pass, release_server.py:611-632): everything behind the LAST layer's cache write - its q projection,
                                attention, o-projection, cross-attention, FFN, the head - is skipped, `out` is left untouched */

@@ -61,7 +61,7 @@ class _Step(ctypes.Structure):
                 ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int),
                 ("row_begin", ctypes.c_int), ("row_count", ctypes.c_int),
                 ("ring_lo", ctypes.c_int), ("ring_size", ctypes.c_int), ("ring_shift", ctypes.c_int),
-                ("kv_only", ctypes.c_int)]
+                ("text_rows", ctypes.c_int), ("kv_only", ctypes.c_int)]
 
 
 _lib.EXTRA_SIGNATURES["rtv_dit_forward"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step),
@@ -154,6 +154,9 @@ class CausalWanModel:
         self._tensors = {}      # name -> device tensor (keeps the memory alive)
         self._w = None          # ctypes weight table
         self._ws = {}           # (F, gh, gw) -> workspace tensor
+        # cross-attention over the real prompt rows + ONE of the (identical) zero-padding rows weighted by their count instead of
+        # all 512 text rows (rtv_attn_fwd_dup: mathematically identical, 8x less cross-attention work for a 64-token prompt)
+        self.fold_text_padding = True
         self.use_hip_graphs = False   # replay each distinct forward (recompute / denoise step) from a captured hipGraph
         self._graphs = {}
         self._weights_version = 0     # part of the graph key: a captured graph embeds weight pointers and the launch sequence
@@ -443,12 +446,22 @@ class CausalWanModel:
             cu = context[0] if not torch.is_tensor(context) else context[0]
             ctx = torch.zeros(self.text_len, self.text_dim, dtype=torch.bfloat16, device=u.device)
             ctx[:cu.shape[0]] = cu.to(torch.bfloat16)
+            # Rows behind the last non-zero row of the (zero-padded, utils/wan_wrapper.py:52-53) prompt embedding all get the SAME
+            # cross-attention K / V row - text MLP, k / v projection and k-norm act per row - so the cross-attention may attend
+            # ONE of them with weight text_len - n_real (rtv_attn_fwd_dup).  One host sync per prompt, remembered on the caches.
+            nz = torch.nonzero(ctx.abs().amax(dim=1) > 0)
+            n_real = int(nz[-1]) + 1 if nz.numel() else 0
+            for c in crossattn_cache:
+                c["text_rows"] = n_real
         cp = self.context_parallel
         use_cp = cp is not None and cp.world > 1
         # `kv_cache_only` (set by the session around its KV-recompute pass, whose output the reference discards as well,
         # release_server.py:611-632): the forward stops behind the last layer's K / V cache write; the returned tensor is zeros
         # (not while the cross-attention caches are still to be filled: the last layer's text K / V are computed in its rest phase)
         kv_only = bool(getattr(self, "kv_cache_only", False)) and not need_cross
+        text_rows = int(crossattn_cache[0].get("text_rows", 0)) if getattr(self, "fold_text_padding", True) else 0
+        if text_rows <= 0 or any(int(c.get("text_rows", 0)) != text_rows for c in crossattn_cache):
+            text_rows = 0        # unknown (caches filled elsewhere) or inconsistent: attend all text_len rows
         row0, lo, hi, start_frame, causal_block, (ring_lo, ring_size, ring_shift), commit = \
             self._cache_window(kv_cache, M, current_start, fs, ring=not use_cp)
         L = self.num_layers
@@ -477,7 +490,7 @@ class CausalWanModel:
             st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
                        F, gh, gw, kk, kv, rs, ck, cv, int(need_cross), row0, lo, hi,
                        start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1],
-                       ring_lo, ring_size, ring_shift, int(kv_only))
+                       ring_lo, ring_size, ring_shift, int(text_rows), int(kv_only))
             return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
 
         if self.gemm_tile_cfg in (0, 5):
@@ -490,7 +503,7 @@ class CausalWanModel:
                 # the ~530 launches of one forward replayed as ONE hipGraph.  Everything the launch sequence
                 # depends on is part of the key (steady state has two entries: the recompute pass and the denoise step);
                 # the latent / timestep / output live in static buffers.  The first sighting of a key runs eagerly.
-                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, ring_lo, ring_size, ring_shift, kv_only,
+                graph_key = (F, gh, gw, row0, lo, hi, start_frame, causal_block, ring_lo, ring_size, ring_shift, kv_only, text_rows,
                              int(self.gemm_tile_cfg), rs, self._weights_version,
                              kv_cache[0]["k"].data_ptr(), kv_cache[-1]["v"].data_ptr(), crossattn_cache[0]["k"].data_ptr())
                 ent = self._graphs.get(graph_key)

@@ -37,6 +37,10 @@ struct AttnParams {
   int n0, delta;
   int off0;   // four-phase kernel only: keys v < n0 are cache rows v + off0 (its k / v point at the lowest row of the window)
   int skip_idle;  // four-phase kernel only: waves whose 32 query rows all lie beyond Lq run the idle loop (A/B switch)
+  // lockstep kernel only: key `dup_key` stands for dup_count identical keys (the zero-padded text rows of the cross-attention all
+  // have the same K and V): its score gets + dup_bias = log2(dup_count) / scale_log2e before the softmax.  -1: none.
+  int dup_key;
+  float dup_bias;
 };
 
 constexpr int ATT_D = 128;
@@ -258,6 +262,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
       }
 
     ATT_STAMP(1);
+    // ---------------- a key that stands for several identical ones: + log2(count) in the exponent (kernel-uniform test)
+    if (p.dup_key >= 0 && (unsigned)(p.dup_key - j * ATT_KT) < (unsigned)ATT_KT) {
+      const int local = p.dup_key - j * ATT_KT;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * g == local) sacc[kbk][r] += p.dup_bias;
+    }
     // ---------------- mask (only on tiles that cross a limit of this wave)
     if ((j + 1) * ATT_KT > wave_min_lim) {
 #pragma unroll
@@ -798,11 +811,37 @@ extern "C" int rtv_attn_fwd(const void* q, const void* k, const void* v, void* o
                           stream);
 }
 
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
+                         int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
+                         int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
+                         int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
+                         int causal_block, int q_offset, int dtype, rtv_stream_t stream, int dup_key, int dup_count);
+
 extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
                                 int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
                                 int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
                                 int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
                                 int causal_block, int q_offset, int dtype, rtv_stream_t stream) {
+  return attn_fwd_impl(q, k, v, o, B, Lq, Lkv0, Lkv1, seg1_row, H, D, q_batch_stride, q_row_stride, k_batch_stride, k_row_stride,
+                       v_batch_stride, v_row_stride, o_batch_stride, o_row_stride, scale, causal_block, q_offset, dtype, stream,
+                       -1, 0);
+}
+
+extern "C" int rtv_attn_fwd_dup(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv, int H, int D,
+                                int64_t q_batch_stride, int64_t q_row_stride, int64_t k_batch_stride, int64_t k_row_stride,
+                                int64_t v_batch_stride, int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride,
+                                float scale, int dup_key, int dup_count, int dtype, rtv_stream_t stream) {
+  if (dup_key < 0 || dup_key >= Lkv || dup_count < 1) return set_error(-1, "attn_fwd_dup: dup_key must be a key of the window, dup_count >= 1");
+  return attn_fwd_impl(q, k, v, o, B, Lq, Lkv, 0, 0, H, D, q_batch_stride, q_row_stride, k_batch_stride, k_row_stride,
+                       v_batch_stride, v_row_stride, o_batch_stride, o_row_stride, scale, 0, 0, dtype, stream,
+                       dup_count > 1 ? dup_key : -1, dup_count);
+}
+
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
+                         int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
+                         int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
+                         int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
+                         int causal_block, int q_offset, int dtype, rtv_stream_t stream, int dup_key, int dup_count) {
   if (Lkv0 < 0 || Lkv1 < 0) return set_error(-1, "attn_fwd: negative segment length");
   if (Lkv1 > 0 && causal_block > 0) return set_error(-1, "attn_fwd: the block-causal mask needs a one-segment window");
   const int Lkv = Lkv0 + Lkv1;
@@ -834,6 +873,8 @@ extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, voi
   p.o_bs = o_batch_stride;
   p.o_rs = o_row_stride;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.dup_key = dup_key;
+  p.dup_bias = dup_key >= 0 ? log2f((float)dup_count) / p.scale_log2e : 0.f;
   p.causal_block = causal_block;
   p.q_offset = q_offset;
   p.n0 = Lkv1 > 0 ? Lkv0 : Lkv;
@@ -874,7 +915,7 @@ extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, voi
                            ((top0 > top1 ? top0 : top1) + ATT_KT) * rs_max * 2 < 0x7fffffffLL;
   // Short key windows (the 512-key cross-attention) stay on the lockstep kernel: the four-phase one stages two tiles before its
   // first MFMA and pays four barriers per tile (measured 93 vs 84 us at 4680 x 512 x 40; +1..4 % from 4680 keys on).
-  if (waves == 8 && !g_attn_lockstep && offsets_fit && (Lkv >= 1024 || g_attn_force_pp)) {
+  if (waves == 8 && !g_attn_lockstep && offsets_fit && dup_key < 0 && (Lkv >= 1024 || g_attn_force_pp)) {
     p.k += (int64_t)base_shift * k_row_stride;
     p.v += (int64_t)base_shift * v_row_stride;
     p.off0 = -base_shift;

@@ -313,8 +313,12 @@ static int dit_after_attn(Ctx& c, int l) {
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, nullptr, nullptr, 0, 0, 0, lw.norm3_w, lw.norm3_b, stream));
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_CQ, b.xn, d, lw.cq_w, lw.cq_b, b.qkv, rc, d, 0, nullptr, 0, 0, 0, nullptr, tc, stream));
   RTV_TRY(rtv_rmsnorm(b.qkv, d, b.q, d, rc, d, eps, lw.cnorm_q_w, stream));
-  RTV_TRY(rtv_attn_fwd(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, rc, c.cfg->text_len, H, hd, 0, d, 0, d, 0, d, 0, d,
-                       scale, 0, 0, RTV_DTYPE_BF16, stream));
+  if (st->text_rows > 0 && st->text_rows + 1 < c.cfg->text_len)   // the padding rows share one K / V row: attend it once, weighted
+    RTV_TRY(rtv_attn_fwd_dup(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, rc, st->text_rows + 1, H, hd, 0, d, 0, d, 0, d, 0, d, scale,
+                             st->text_rows, c.cfg->text_len - st->text_rows, RTV_DTYPE_BF16, stream));
+  else
+    RTV_TRY(rtv_attn_fwd(b.q, st->ca_k[l], st->ca_v[l], b.ao, 1, rc, c.cfg->text_len, H, hd, 0, d, 0, d, 0, d, 0, d,
+                         scale, 0, 0, RTV_DTYPE_BF16, stream));
   RTV_TRY(linear(c, S_LAYER0 + S_PER_LAYER * l + S_CO, b.ao, d, lw.co_w, lw.co_b, b.x, rc, d, 0, nullptr, 0, 0, 0, b.x, tc, stream));
   // FFN (causal_model.py:482-488)
   RTV_TRY(rtv_layernorm_modulate(b.x, b.xn, rc, d, eps, em + 3 * d, em + 4 * d, 6 * d, fs, r0, nullptr, nullptr, stream));

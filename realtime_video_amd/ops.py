@@ -87,6 +87,26 @@ def attn_fwd(q, k, v, out=None, scale=None, causal_block=0, q_offset=0):
     return out
 
 
+def attn_fwd_dup(q, k, v, dup_key, dup_count, out=None, scale=None):
+    """Dense attention in which key `dup_key` of the window stands for `dup_count` identical keys (rtv_attn_fwd_dup)."""
+    _gpu(q, k, v)
+    B, Lq, H, D = q.shape
+    Lkv = k.shape[1]
+    if k.shape != v.shape or k.shape[0] != B or k.shape[2] != H or k.shape[3] != D:
+        raise ValueError(f"attention shape mismatch q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("attention operands need dense [H, D] inner dims (BLHD layout)")
+    if out is None:
+        out = torch.empty((B, Lq, H, D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    _lib.call("rtv_attn_fwd_dup", _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Lq, Lkv, H, D,
+              q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+              out.stride(0), out.stride(1), float(scale), int(dup_key), int(dup_count), _dt(q), _stream())
+    return out
+
+
 def attn_fwd_win(q, k_cache, v_cache, seg0, seg1=(0, 0), out=None, scale=None):
     """Attention over a key window made of two row ranges of a cache (rtv_attn_fwd_win): k_cache / v_cache [B, rows, H, 128],
     seg = (first_row, n_rows).  How a ring-indexed rolling KV cache is attended without the reference's shift copy."""

@@ -656,6 +656,38 @@ def test_fp8_context_parallel_matches_row_sharded_fp8_oracle(exchange):
         assert 0 < rel_l2(sharded, whole) <= 5e-2
 
 
+def test_cross_attention_padding_fold_matches_full_text_window(golden):
+    """`fold_text_padding` (default): the cross-attention attends the real prompt rows plus ONE of the zero-padding rows weighted by
+    their count (all padding rows have the same cached K / V row) instead of all 512 text rows.  Against the same model with the
+    switch off - server-path sequence of the reference golden (64 prompt rows of 512): rel-L2 <= 3e-3 on every output, the text
+    K / V caches are bit-identical, the padding rows of the cache really are identical rows - and both are within the golden
+    tolerance of the reference."""
+    from oracle import wan_oracle as wo
+    g = golden("dit_server_path.pt")
+    cfg, text_dim, tiny_inputs = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    lat, ctx = tiny_inputs()
+    t = torch.ones([1, 3], dtype=torch.int64) * g["steps"][0]
+    outs = {}
+    for fold in (True, False):
+        model, wr = _build(cfg, text_dim, w)
+        model.fold_text_padding = fold
+        kv, ca = _caches(cfg, 9360)
+        cond = {"prompt_embeds": [ctx.to(DEV)]}
+        a, _ = wr(lat[0].to(DEV), cond, t.to(DEV), kv, ca, current_start=0)
+        b, _ = wr(lat[3].to(DEV), cond, t.to(DEV), kv, ca, current_start=4680)
+        assert ca[0].get("text_rows") == ctx.shape[0]
+        outs[fold] = (a, b, [c["k"].clone() for c in ca], [c["v"].clone() for c in ca])
+    for i in range(2):
+        assert rel_l2(outs[True][i], outs[False][i]) <= 3e-3
+    assert rel_l2(outs[True][0].cpu(), g["b0s0_flow"]) <= 2e-2 and rel_l2(outs[False][0].cpu(), g["b0s0_flow"]) <= 2e-2
+    for x, y in zip(outs[True][2] + outs[True][3], outs[False][2] + outs[False][3]):
+        assert torch.equal(x, y)
+    n = ctx.shape[0]
+    for kc in outs[True][2] + outs[True][3]:
+        assert torch.equal(kc[0, n:], kc[0, n:n + 1].expand_as(kc[0, n:]))      # every padding row is the same row
+
+
 @pytest.mark.parametrize("cp_world", [0, 2])
 def test_kv_cache_only_forward_fills_the_same_cache(cp_world):
     """`model.kv_cache_only` (what the session sets around its KV-recompute pass, whose output the reference discards,

@@ -471,6 +471,29 @@ def test_gemm_full_14b_shapes(ops, name, N, K, act):
         assert rel_l2(lin, (ref.float() - b.float())) <= 1e-2
 
 
+@pytest.mark.parametrize("Lq,n_real,total,H", [(4680, 64, 512, 4), (300, 1, 512, 2), (257, 200, 512, 3), (100, 63, 70, 1), (585, 64, 65, 2)])
+def test_attention_duplicate_key_equals_repeated_keys(ops, Lq, n_real, total, H):
+    """rtv_attn_fwd_dup (the text cross-attention without its redundant work, model.py:171-228): a window of n_real keys plus ONE
+    key counted (total - n_real) times equals dense attention over the window with that key repeated - mathematically; in floating
+    point the two differ by summation order and the bf16 rounding of P: both within the attention tolerance of the fp32 definition,
+    and within 4e-3 of each other.  count == 1 is plain attention (bit-identical)."""
+    q = _randn(1, Lq, H, 128, seed=1)
+    k = _randn(1, n_real + 1, H, 128, seed=2)
+    v = _randn(1, n_real + 1, H, 128, seed=3)
+    count = total - n_real
+    kk = torch.cat([k[:, :n_real], k[:, n_real:].expand(-1, count, -1, -1)], 1).contiguous()
+    vv = torch.cat([v[:, :n_real], v[:, n_real:].expand(-1, count, -1, -1)], 1).contiguous()
+    full = ops.attn_fwd(q, kk, vv)
+    fold = ops.attn_fwd_dup(q, k, v, n_real, count)
+    ref = _attn_ref(q, kk, vv)
+    assert max_abs(full, ref) <= 2e-2 and max_abs(fold, ref) <= 2e-2
+    assert max_abs(fold, full) <= 4e-3 + 1e-2 * float(ref.abs().max()) and rel_l2(fold, full) <= 5e-3
+    if count == 1:
+        assert torch.equal(fold, full)
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd_dup(q, k, v, n_real + 1, 3)             # dup_key outside the window
+
+
 def test_idle_wave_loops_change_nothing_but_the_time(ops):
     """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
     only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
