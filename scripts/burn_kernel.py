@@ -1,4 +1,4 @@
-"""Run one hot kernel back to back for N seconds (for scripts/power_clock_sample.sh).  usage: burn_kernel.py gemm|attn|conv [seconds]"""
+"""Run one hot kernel back to back for N seconds (for scripts/power_clock_sample.sh).  usage: burn_kernel.py gemm|gemm_fp8|attn|conv [seconds]"""
 import ctypes
 import os
 import sys
@@ -16,6 +16,14 @@ if which == "gemm":
     w = (torch.randn(15360, 5120, device=dev) * 5120 ** -0.5).to(torch.bfloat16)
     out = torch.empty(4680, 15360, device=dev, dtype=torch.bfloat16)
     fn, flop = (lambda: ops.gemm(a, w, out=out)), 2.0 * 4680 * 15360 * 5120
+elif which == "gemm_fp8":
+    a = torch.randn(4680, 5120, device=dev).to(torch.bfloat16)
+    w = (torch.randn(15360, 5120, device=dev) * 5120 ** -0.5)
+    sw = float(w.abs().max()) / 448.0
+    wq = (w / sw).clamp(-448, 448).to(torch.float8_e4m3fn)
+    aq, sa = ops.quantize_fp8(a)
+    out = torch.empty(4680, 15360, device=dev, dtype=torch.bfloat16)
+    fn, flop = (lambda: ops.gemm_fp8(aq, sa, wq, sw, out=out)), 2.0 * 4680 * 15360 * 5120
 elif which == "attn":
     q = torch.randn(1, 4680, 40, 128, device=dev).to(torch.bfloat16)
     k = torch.randn(1, 9360, 40, 128, device=dev).to(torch.bfloat16)
