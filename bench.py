@@ -148,6 +148,10 @@ def main():
     ap.add_argument("--cp-exchange", default="auto", choices=["auto", "heads", "rows"],
                     help="context-parallel exchange around self-attention: heads = all-to-all pair (head-sharded KV cache), "
                          "rows = K/V all-gather (replicated cache); auto = heads when the head count divides")
+    ap.add_argument("--cp-attn-splits", type=int, default=0,
+                    help="context parallel: cut every rank's self-attention launch along the keys into this many ranges "
+                         "(rtv_attn_fwd_split; 1 = one launch, bit-identical with the unsharded forward; 0 = 2 when a rank's "
+                         "launch has fewer than 128 workgroups - 8 ranks of the 14B model: 95 - else 1)")
     ap.add_argument("--no-cp-overlap", action="store_true",
                     help="A/B: complete every context-parallel collective before the next kernel is issued (default: the "
                          "q all-to-all runs under the k|v projection / the K/V all-gather under the q projection)")
@@ -214,12 +218,16 @@ def main():
     if args.fp8:
         model.enable_fp8()
     use_cp = world > 1 and args.parallel == "cp"
+    cp_world = world if use_cp else max(1, args.simulate_cp)
+    if args.cp_attn_splits <= 0:   # workgroups of one rank's launch: heads x 256-row query tiles / ranks (either exchange)
+        args.cp_attn_splits = 2 if cp_world > 1 and mc["num_heads"] * 19 // cp_world < 128 else 1
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
-        model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap)
+        model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap,
+                                                 attn_kv_splits=args.cp_attn_splits)
     if args.simulate_cp > 1:
         from realtime_video_amd.parallel import SimulatedContextParallel
-        model.context_parallel = SimulatedContextParallel(args.simulate_cp, args.cp_exchange)
+        model.context_parallel = SimulatedContextParallel(args.simulate_cp, args.cp_exchange, attn_kv_splits=args.cp_attn_splits)
         args.no_vae = True
     wr = WanDiffusionWrapper(model, timestep_shift=5.0)
 
@@ -364,6 +372,7 @@ def main():
                 + "; VAE decode "
                 f"sharded by output rows ({world} stripes + conv halos, one pixel all-gather per block), first-frame "
                 f"re-encode replicated" if use_cp else f"{world} independent replicas"),
+            "cp_attn_kv_splits": args.cp_attn_splits if (use_cp or args.simulate_cp > 1) else None,
             "dit_ms_per_denoise_step": sum(step_ms) / max(1, len(step_ms)),        # BASELINE.json "per-step DiT latency"
             "dit_ms_per_recompute_forward": sum(recompute_ms) / max(1, len(recompute_ms)) if recompute_ms else None,
             # kernel-class times exist only for the classes bracketed with events (--profile-classes; 'all' = diagnostic)

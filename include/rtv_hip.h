@@ -82,6 +82,23 @@ int rtv_attn_fwd_dup(const void* q, const void* k, const void* v, void* o,
                      int64_t v_batch_stride, int64_t v_row_stride,
                      int64_t o_batch_stride, int64_t o_row_stride,
                      float scale, int dup_key, int dup_count, int dtype, rtv_stream_t stream);
+/* KV split of rtv_attn_fwd_win for launches whose query grid cannot fill 256 CUs (the head-parallel phase of a context-parallel
+ * rank: 5 heads x 19 query tiles = 95 workgroups; wan/distributed/xdit_context_parallel.py:179 runs that attention through
+ * xfuser's USP): the key window is cut into kv_splits ranges of 64-key tiles, one workgroup per (head, query tile, range); each
+ * leaves its unnormalised fp32 output and its (reference point, row sum) in `workspace`, a second kernel merges them
+ * (m = max m_s, O = sum 2^(m_s - m) O_s / sum 2^(m_s - m) l_s) and writes `o`.  Arguments as rtv_attn_fwd_win (a block-causal
+ * launch splits every workgroup's own key-tile count).
+ * Same mathematics as the unsplit launch; the fp32 summation order differs (stated tolerance in the tests: the split result is
+ * within 2 bf16 ulps of the unsplit one).  workspace: rtv_attn_split_workspace_bytes(B, Lq, H, kv_splits), 16-byte aligned. */
+size_t rtv_attn_split_workspace_bytes(int B, int Lq, int H, int kv_splits);
+int rtv_attn_fwd_split(const void* q, const void* k, const void* v, void* o,
+                       int B, int Lq, int Lkv0, int Lkv1, int seg1_row, int H, int D,
+                       int64_t q_batch_stride, int64_t q_row_stride,
+                       int64_t k_batch_stride, int64_t k_row_stride,
+                       int64_t v_batch_stride, int64_t v_row_stride,
+                       int64_t o_batch_stride, int64_t o_row_stride,
+                       float scale, int causal_block, int q_offset,
+                       int kv_splits, void* workspace, size_t workspace_bytes, int dtype, rtv_stream_t stream);
 /* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
  * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  256-row launches over >= 1024 keys run the
  * four-phase kernel (K/V by LDS DMA, fragments read a phase ahead of their MFMAs, the two wave groups one phase apart),
@@ -253,6 +270,9 @@ typedef struct rtv_dit_step {
   int kv_only;              /* 1: the caller only wants the KV cache filled and discards the output (the session's KV-recompute
                                pass, release_server.py:611-632): everything behind the LAST layer's cache write - its q projection,
                                attention, o-projection, cross-attention, FFN, the head - is skipped, `out` is left untouched */
+  int attn_kv_splits;       /* > 1: the self-attention launches of a token- or head-sharded call (rtv_dit_layer_attn_hp,
+                               rtv_dit_layer_rest with row_count < M) cut their key window into this many ranges
+                               (rtv_attn_fwd_split); 0 / 1: one launch.  Not bit-identical with the unsplit forward. */
 } rtv_dit_step;
 
 size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw);

@@ -36,6 +36,9 @@ SIGNATURES = {
     "rtv_attn_fwd_dup": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
                          c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                          c_f32, c_int, c_int, c_int, c_vp],
+    "rtv_attn_fwd_split": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                           c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                           c_f32, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_int, c_vp],
     "rtv_attn_set_waves": [c_int],
     "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
                  c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],

@@ -61,7 +61,8 @@ class _Step(ctypes.Structure):
                 ("causal_block", ctypes.c_int), ("gemm_tile_cfg", ctypes.c_int),
                 ("row_begin", ctypes.c_int), ("row_count", ctypes.c_int),
                 ("ring_lo", ctypes.c_int), ("ring_size", ctypes.c_int), ("ring_shift", ctypes.c_int),
-                ("text_rows", ctypes.c_int), ("kv_only", ctypes.c_int)]
+                ("text_rows", ctypes.c_int), ("kv_only", ctypes.c_int),
+                ("attn_kv_splits", ctypes.c_int)]
 
 
 _lib.EXTRA_SIGNATURES["rtv_dit_forward"] = [ctypes.POINTER(_Cfg), ctypes.POINTER(_Weights), ctypes.POINTER(_Step),
@@ -490,7 +491,8 @@ class CausalWanModel:
             st = _Step(u.data_ptr(), tt.data_ptr(), ctx.data_ptr() if ctx is not None else None, out.data_ptr(),
                        F, gh, gw, kk, kv, rs, ck, cv, int(need_cross), row0, lo, hi,
                        start_frame, causal_block, int(self.gemm_tile_cfg), rank_rows[0], rank_rows[1],
-                       ring_lo, ring_size, ring_shift, int(text_rows), int(kv_only))
+                       ring_lo, ring_size, ring_shift, int(text_rows), int(kv_only),
+                       int(getattr(cp, "attn_kv_splits", 1)) if use_cp else 1)
             return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
 
         if self.gemm_tile_cfg in (0, 5):

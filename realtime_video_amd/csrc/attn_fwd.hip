@@ -41,6 +41,14 @@ struct AttnParams {
   // have the same K and V): its score gets + dup_bias = log2(dup_count) / scale_log2e before the softmax.  -1: none.
   int dup_key;
   float dup_bias;
+  // KV split (flash-decoding style, for launches whose query grid cannot fill the chip: the head-parallel phase of a context-
+  // parallel rank has 5 heads x 19 query tiles): blockIdx.y = split s works on key tiles [ntiles*s/S, ntiles*(s+1)/S) of the
+  // workgroup's OWN tile count (block-causal: the tiles below its largest key limit) and leaves its UNNORMALISED O (fp32), its
+  // reference point m and its row sum l in part_o / part_ml; attn_combine_kernel merges.  A row whose keys in a range are all
+  // masked leaves (m, l, O) = (-1e30, 0, 0): weight 2^(-1e30 - m) = 0 in the merge.
+  int kv_splits;    // S (1: the kernel writes `o` itself)
+  float* part_o;    // [S][B*H][Lq][128]
+  float* part_ml;   // [S][B*H][Lq][2] = (m, l)
 };
 
 constexpr int ATT_D = 128;
@@ -91,6 +99,66 @@ __device__ unsigned* g_attn_trace = nullptr;   // [512 blocks][2 waves][4 tiles]
 #else
 #define ATT_STAMP(i)
 #endif
+
+// KV split: this workgroup's share of the key tiles (wave-uniform).
+__device__ __forceinline__ void split_tile_range(const AttnParams& p, int ntiles, int* t_lo, int* t_hi) {
+  *t_lo = 0;
+  *t_hi = ntiles;
+  if (p.kv_splits > 1) {
+    const int s = blockIdx.y;
+    *t_lo = ntiles * s / p.kv_splits;
+    *t_hi = ntiles * (s + 1) / p.kv_splits;
+  }
+}
+
+// KV split epilogue: O^T unnormalised, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}; (m, l) once per row.
+__device__ __forceinline__ void store_partial(const AttnParams& p, int bh, int q_row, int g, const f32x16 (&oacc)[4], float m_run,
+                                              float l_tot) {
+  if (q_row >= p.Lq) return;
+  const size_t row = ((size_t)blockIdx.y * (p.B * p.H) + bh) * p.Lq + q_row;
+  float* po = p.part_o + row * ATT_D + 4 * g;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *(f32x4*)(po + db * 32 + i * 8) = f32x4{oacc[db][4 * i], oacc[db][4 * i + 1], oacc[db][4 * i + 2], oacc[db][4 * i + 3]};
+  if (g == 0) *(f32x2*)(p.part_ml + row * 2) = f32x2{m_run, l_tot};
+}
+
+// Merge of the S partial results of a row: m = max m_s, w_s = 2^(m_s - m), O = sum w_s O_s / sum w_s l_s.
+// 16 threads per row (8 dims each), 16 rows per workgroup.
+template <bool F16>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                           uint16_t* __restrict__ o, int S, int B, int H, int Lq, int64_t o_bs,
+                                                           int64_t o_rs) {
+  const int64_t nrows = (int64_t)B * H * Lq;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (row >= nrows) return;
+  const int c8 = (threadIdx.x & 15) * 8;
+  float m = -INFINITY;
+  for (int s = 0; s < S; ++s) m = fmaxf(m, part_ml[((int64_t)s * nrows + row) * 2]);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float l = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const f32x2 ml = *(const f32x2*)(part_ml + ((int64_t)s * nrows + row) * 2);
+    const float w = __builtin_amdgcn_exp2f(ml[0] - m);
+    l += w * ml[1];
+    const float* po = part_o + ((int64_t)s * nrows + row) * ATT_D + c8;
+    const f32x4 a = *(const f32x4*)po, b2 = *(const f32x4*)(po + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += w * a[i];
+      acc[4 + i] += w * b2[i];
+    }
+  }
+  const float inv = 1.0f / l;
+  const int bh = (int)(row / Lq), q = (int)(row - (int64_t)bh * Lq);
+  const int b = bh / H, h = bh - b * H;
+  u32x4 out;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = pack2<F16>(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+  *(u32x4*)(o + (size_t)b * o_bs + (size_t)q * o_rs + (size_t)h * ATT_D + c8) = out;
+}
 
 template <bool F16, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
@@ -154,6 +222,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
     wg_max_lim = min(p.Lkv, ((p.q_offset + last) / cb + 1) * cb);
   }
   const int ntiles = (wg_max_lim + ATT_KT - 1) / ATT_KT;
+  int t_lo, t_hi;
+  split_tile_range(p, ntiles, &t_lo, &t_hi);
 
   // ---- staging geometry: thread moves chunks id = tid + i*THREADS -> (row = id>>4 = tid>>4 + RSTEP i, chunk = tid&15).
   //      Full tiles: uniform 64-bit base (SGPR, advanced per tile / per i) + one 32-bit lane offset per operand,
@@ -243,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
 #endif
   auto tile = [&](const int j, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
-    const bool has_next = (j + 1 < ntiles);
+    const bool has_next = (j + 1 < t_hi);
     ATT_STAMP(0);
     if (has_next) load_tile(j + 1);  // in flight during the MFMAs below
 
@@ -341,16 +411,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
     ATT_STAMP(5);
   };
 
-  load_tile(0);
+  load_tile(t_lo);
   write_tile(0);
   __syncthreads();
-  for (int j = 0; j < ntiles; j += 2) {
+  for (int j = t_lo; j < t_hi; j += 2) {
     tile(j, IntC<0>{});
-    if (j + 1 < ntiles) tile(j + 1, IntC<1>{});
+    if (j + 1 < t_hi) tile(j + 1, IntC<1>{});
   }
 
   // ---------------- epilogue: O = O^T / l, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (p.kv_splits > 1) {
+    store_partial(p, bh, q_row, g, oacc, m_run, l_tot);
+    return;
+  }
   const float inv = 1.0f / l_tot;
   if (q_row < p.Lq) {
     uint16_t* op = ob + (size_t)q_row * p.o_rs + 4 * g;
@@ -494,6 +568,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
     wg_max_lim = min(p.Lkv, ((p.q_offset + last) / cb + 1) * cb);
   }
   const int ntiles = (wg_max_lim + ATT_KT - 1) / ATT_KT;
+  int t_lo, t_hi;
+  split_tile_range(p, ntiles, &t_lo, &t_hi);
 
   // ---- DMA staging: wave w moves tile rows 8w .. 8w+7 of K and of V, two 1-KiB pieces (4 rows) each.  Lane l lands at byte
   //      16 l of the piece = row (l >> 4), chunk position (l & 15); it fetches the chunk that belongs there:
@@ -544,10 +620,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
   auto stage_v = [&](int j) { stage(rsrcV, sV, j, v_rs, v_fast, v_ch); };
 
   // ---- prologue: tiles 0 and 1 of both operands, Q^T fragments (MFMA B operand): lane holds Q[q][dc*16 + g*8 .. +8]
-  stage_k(0);
-  stage_v(0);
-  stage_k(1);
-  stage_v(1);
+  stage_k(t_lo);
+  stage_v(t_lo);
+  stage_k(t_lo + 1);
+  stage_v(t_lo + 1);
   u32x4 qf[8];
   {
     const uint16_t* qp = qb + (size_t)q_row_c * p.q_rs + g * 8;
@@ -619,7 +695,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
   // reads, both matrix phases and the softmax - a separate loop, the working waves' loop carries no test for it.
   const bool idle_rows = p.skip_idle && q0 + wave * ATT_QW >= p.Lq;   // wave-uniform
   if (idle_rows) {
-    for (int j = 0; j < ntiles; ++j) {
+    for (int j = t_lo; j < t_hi; ++j) {
       stage_k(j + 2);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       PP_BARRIER();
@@ -632,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
     if (!grp) PP_BARRIER();
     return;
   }
-  for (int j = 0; j < ntiles; ++j) {
+  for (int j = t_lo; j < t_hi; ++j) {
     const int slot_off = (j % ATT_NB) * ATT_TILE_BYTES;
     // ---------------- LK
     ATT_STAMP8(0);
@@ -757,6 +833,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
 #endif
   // ---------------- epilogue: O = O^T / l, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (p.kv_splits > 1) {
+    store_partial(p, bh, q_row, g, oacc, m_run, l_tot);
+    return;
+  }
   const float inv = 1.0f / l_tot;
   if (q_row < p.Lq) {
     uint16_t* op = ob + (size_t)q_row * p.o_rs + 4 * g;
@@ -815,7 +895,8 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
                          int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
                          int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
                          int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
-                         int causal_block, int q_offset, int dtype, rtv_stream_t stream, int dup_key, int dup_count);
+                         int causal_block, int q_offset, int dtype, rtv_stream_t stream, int dup_key, int dup_count,
+                         int kv_splits = 1, void* split_ws = nullptr, size_t split_ws_bytes = 0);
 
 extern "C" int rtv_attn_fwd_win(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
                                 int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
@@ -837,11 +918,29 @@ extern "C" int rtv_attn_fwd_dup(const void* q, const void* k, const void* v, voi
                        dup_count > 1 ? dup_key : -1, dup_count);
 }
 
+extern "C" size_t rtv_attn_split_workspace_bytes(int B, int Lq, int H, int kv_splits) {
+  if (B <= 0 || Lq <= 0 || H <= 0 || kv_splits < 2) return 0;
+  return (size_t)kv_splits * B * H * Lq * (ATT_D + 2) * sizeof(float);
+}
+
+extern "C" int rtv_attn_fwd_split(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
+                                  int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
+                                  int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
+                                  int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
+                                  int causal_block, int q_offset, int kv_splits, void* workspace, size_t workspace_bytes,
+                                  int dtype, rtv_stream_t stream) {
+  if (kv_splits < 1 || kv_splits > 16) return set_error(-1, "attn_fwd_split: kv_splits must be 1..16");
+  return attn_fwd_impl(q, k, v, o, B, Lq, Lkv0, Lkv1, seg1_row, H, D, q_batch_stride, q_row_stride, k_batch_stride, k_row_stride,
+                       v_batch_stride, v_row_stride, o_batch_stride, o_row_stride, scale, causal_block, q_offset, dtype, stream, -1,
+                       0, kv_splits, workspace, workspace_bytes);
+}
+
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, int B, int Lq, int Lkv0, int Lkv1,
                          int seg1_row, int H, int D, int64_t q_batch_stride, int64_t q_row_stride,
                          int64_t k_batch_stride, int64_t k_row_stride, int64_t v_batch_stride,
                          int64_t v_row_stride, int64_t o_batch_stride, int64_t o_row_stride, float scale,
-                         int causal_block, int q_offset, int dtype, rtv_stream_t stream, int dup_key, int dup_count) {
+                         int causal_block, int q_offset, int dtype, rtv_stream_t stream, int dup_key, int dup_count,
+                         int kv_splits, void* split_ws, size_t split_ws_bytes) {
   if (Lkv0 < 0 || Lkv1 < 0) return set_error(-1, "attn_fwd: negative segment length");
   if (Lkv1 > 0 && causal_block > 0) return set_error(-1, "attn_fwd: the block-causal mask needs a one-segment window");
   const int Lkv = Lkv0 + Lkv1;
@@ -875,6 +974,20 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   p.scale_log2e = scale * 1.4426950408889634f;
   p.dup_key = dup_key;
   p.dup_bias = dup_key >= 0 ? log2f((float)dup_count) / p.scale_log2e : 0.f;
+  // never more splits than key tiles; one split = the plain launch
+  if (kv_splits > (Lkv + ATT_KT - 1) / ATT_KT) kv_splits = (Lkv + ATT_KT - 1) / ATT_KT;
+  if (kv_splits < 1) kv_splits = 1;
+  p.kv_splits = kv_splits;
+  p.part_o = nullptr;
+  p.part_ml = nullptr;
+  if (kv_splits > 1) {
+    if (dup_key >= 0) return set_error(-1, "attn_fwd: no KV split of a window with a counted key");
+    const size_t rows = (size_t)kv_splits * B * H * Lq;
+    if (!split_ws || ((uintptr_t)split_ws & 15) || split_ws_bytes < rows * (ATT_D + 2) * sizeof(float))
+      return set_error(-1, "attn_fwd: split workspace missing, misaligned or too small (rtv_attn_split_workspace_bytes)");
+    p.part_o = (float*)split_ws;
+    p.part_ml = p.part_o + rows * ATT_D;
+  }
   p.causal_block = causal_block;
   p.q_offset = q_offset;
   p.n0 = Lkv1 > 0 ? Lkv0 : Lkv;
@@ -886,7 +999,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   // 128-row / 4-wave workgroups (two per CU) when the 256-row grid cannot fill the chip, and for short key windows (the
   // text cross-attention, 512 keys = 8 tiles): a workgroup is then mostly prologue and epilogue, which two co-resident
   // workgroups overlap (scripts/cross_attn_ab.py: 74.9 vs 79.0 us at 4680 x 512 x 40 heads; bit-identical)
-  if (waves == 0) waves = ((int64_t)B * H * ((Lq + 255) / 256) < 160 || Lkv <= 512) ? 4 : 8;
+  if (waves == 0) waves = ((int64_t)B * H * ((Lq + 255) / 256) * kv_splits < 160 || Lkv <= 512) ? 4 : 8;
   const int qt_rows = ATT_QW * waves;
   p.n_qtiles = (Lq + qt_rows - 1) / qt_rows;
   const int lds = 4 * ATT_TILE_BYTES;
@@ -903,7 +1016,15 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   const int grid = B * H * p.n_qtiles;
   double kv_avg = Lkv;  // dense; block-causal work is smaller (reported as dense upper bound / 1)
   ProfScope prof(PROF_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Lq * kv_avg * ATT_D);
-  const dim3 g(grid), t(waves * 64);
+  const dim3 g(grid, kv_splits), t(waves * 64);
+  auto combine = [&]() -> int {
+    if (int st = check_launch("attn_fwd")) return st;
+    const int64_t nrows = (int64_t)B * H * Lq;
+    const dim3 cg((unsigned)((nrows + 15) / 16)), ct(256);
+    if (f16) hipLaunchKernelGGL((attn_combine_kernel<true>), cg, ct, 0, (hipStream_t)stream, p.part_o, p.part_ml, p.o, kv_splits, B, H, Lq, p.o_bs, p.o_rs);
+    else hipLaunchKernelGGL((attn_combine_kernel<false>), cg, ct, 0, (hipStream_t)stream, p.part_o, p.part_ml, p.o, kv_splits, B, H, Lq, p.o_bs, p.o_rs);
+    return check_launch("attn_combine");
+  };
   // Four-phase kernel: its DMA addresses K / V rows with non-negative 32-bit byte offsets from a buffer base, so the base is
   // the lowest row of the window (the second range of a ring window lies BELOW the first one).
   p.off0 = 0;
@@ -934,6 +1055,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
     }
     if (f16) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), g, t, lds_pp, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), g, t, lds_pp, (hipStream_t)stream, p);
+    if (kv_splits > 1) return combine();
     return check_launch("attn_fwd");
   }
   if (waves == 4) {
@@ -943,5 +1065,6 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
     if (f16) hipLaunchKernelGGL((attn_fwd_kernel<true, 8>), g, t, lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), g, t, lds, (hipStream_t)stream, p);
   }
+  if (kv_splits > 1) return combine();
   return check_launch("attn_fwd");
 }

@@ -40,6 +40,8 @@ struct DitBuffers {
   uint16_t *sinus, *te1, *e, *se, *e0, *emod, *ehead, *ctx1, *ctx, *ktmp;
   uint8_t* q8;      // fp8 path: the quantised activation of the linear being computed
   float* fscale;    // fp8 path: its per-tensor scale (device), followed by the 4-byte absmax scratch
+  float* attn_part; // KV-split self-attention of a sharded call: fp32 partial outputs + (m, l) of splits x heads x rows <= H x M
+  size_t attn_part_bytes;
 };
 
 // Buffers are sized for the full token count so that one workspace serves sharded and unsharded calls.
@@ -74,6 +76,9 @@ static size_t carve(const rtv_dit_config* c, int F, int gh, int gw, char* base, 
     t.q8 = (uint8_t*)ws.take(c->use_fp8 ? rows * k : 0);
     t.fscale = (float*)ws.take(256);
   }
+  // a sharded call attends rows x heads <= M x H / world; with kv_splits <= world the partials of all splits fit M x H rows
+  t.attn_part_bytes = M * (size_t)c->num_heads * (128 + 2) * sizeof(float);
+  t.attn_part = (float*)ws.take(t.attn_part_bytes);
   if (b) *b = t;
   if (ok) *ok = ws.ok;
   return ws.off;
@@ -277,6 +282,20 @@ static KeyWindow key_window(const rtv_dit_step* st) {
   return KeyWindow{sink ? lo : S, sink + n - first, p0, first};
 }
 
+// Self-attention of a sharded call: one launch, or the KV-split one when the step asks for it and the partials fit.
+static int sharded_self_attn(Ctx& c, const void* q, const void* k, const void* v, void* o, int rows, int n0, int n1, int seg1_row,
+                             int heads, int64_t q_rs, int64_t kv_rs, int64_t o_rs, int q_offset) {
+  const rtv_dit_step* st = c.st;
+  const float scale = 1.0f / sqrtf((float)c.hd);
+  const int S = st->attn_kv_splits;
+  const int qo = st->causal_block > 0 ? q_offset : 0;
+  if (S > 1 && rtv_attn_split_workspace_bytes(1, rows, heads, S) <= c.b.attn_part_bytes)
+    return rtv_attn_fwd_split(q, k, v, o, 1, rows, n0, n1, seg1_row, heads, c.hd, 0, q_rs, 0, kv_rs, 0, kv_rs, 0, o_rs, scale,
+                              st->causal_block, qo, S, c.b.attn_part, c.b.attn_part_bytes, RTV_DTYPE_BF16, c.stream);
+  return rtv_attn_fwd_win(q, k, v, o, 1, rows, n0, n1, seg1_row, heads, c.hd, 0, q_rs, 0, kv_rs, 0, kv_rs, 0, o_rs, scale,
+                          st->causal_block, qo, RTV_DTYPE_BF16, c.stream);
+}
+
 // ---- layer, part 2: attention over the cache window -> o-proj(+gate,+res) -> cross-attn -> FFN
 static int dit_layer_rest(Ctx& c, int l) {
   const rtv_dit_step* st = c.st;
@@ -291,9 +310,14 @@ static int dit_layer_rest(Ctx& c, int l) {
   uint16_t* vc = (uint16_t*)st->kv_v[l];
   // self attention (causal_model.py:386-390, :470-476)
   KeyWindow kw = key_window(st);
-  RTV_TRY(rtv_attn_fwd_win(b.q, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, b.ao, 1, rc, kw.n0, kw.n1,
-                           kw.row1 - kw.row0, H, hd, 0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block,
-                           st->causal_block > 0 ? q_offset : 0, RTV_DTYPE_BF16, stream));
+  if (rc < c.M) {   // token-sharded call: the query grid is rc / 256 tiles per head - optionally cut along the keys
+    RTV_TRY(sharded_self_attn(c, b.q, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, b.ao, rc, kw.n0, kw.n1,
+                              kw.row1 - kw.row0, H, d, rs, d, q_offset));
+  } else {
+    RTV_TRY(rtv_attn_fwd_win(b.q, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, b.ao, 1, rc, kw.n0, kw.n1,
+                             kw.row1 - kw.row0, H, hd, 0, d, 0, rs, 0, rs, 0, d, scale, st->causal_block,
+                             st->causal_block > 0 ? q_offset : 0, RTV_DTYPE_BF16, stream));
+  }
   (void)Lkv;
   return dit_after_attn(c, l);
 }
@@ -355,9 +379,8 @@ static int dit_layer_attn_hp(Ctx& c, int l, int world, const void* q_all, void* 
   const uint16_t* vc = (const uint16_t*)st->kv_v[l];
   KeyWindow kw = key_window(st);
   (void)Lkv;
-  return rtv_attn_fwd_win(q_all, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, o_all, 1, c.M, kw.n0, kw.n1,
-                          kw.row1 - kw.row0, hn, c.hd, 0, gc, 0, rs, 0, rs, 0, gc, 1.0f / sqrtf((float)c.hd), st->causal_block,
-                          st->causal_block > 0 ? q_offset : 0, RTV_DTYPE_BF16, c.stream);
+  return sharded_self_attn(c, q_all, kc + (size_t)kw.row0 * rs, vc + (size_t)kw.row0 * rs, o_all, c.M, kw.n0, kw.n1,
+                           kw.row1 - kw.row0, hn, gc, rs, gc, q_offset);
 }
 
 static int dit_layer_rest_hp(Ctx& c, int l, int world, const void* o_recv) {

@@ -130,6 +130,38 @@ def attn_fwd_win(q, k_cache, v_cache, seg0, seg1=(0, 0), out=None, scale=None):
     return out
 
 
+def attn_fwd_split(q, k_cache, v_cache, seg0, seg1=(0, 0), kv_splits=2, out=None, scale=None, workspace=None, causal_block=0,
+                   q_offset=0):
+    """attn_fwd_win with the key window cut into `kv_splits` ranges, one workgroup per (head, query tile, range), merged by a
+    second kernel (rtv_attn_fwd_split): for launches too small to fill the chip.  workspace: fp32 tensor of at least
+    kv_splits * B * H * Lq * 130 elements (allocated when None)."""
+    _gpu(q, k_cache, v_cache)
+    B, Lq, H, D = q.shape
+    (r0, n0), (r1, n1) = seg0, seg1
+    rows = k_cache.shape[1]
+    if min(r0, n0, r1, n1) < 0 or r0 + n0 > rows or (n1 and r1 + n1 > rows):
+        raise ValueError("attn_fwd_split: segment outside the cache")
+    for t in (q, k_cache, v_cache):
+        if t.stride(3) != 1 or t.stride(2) != D:
+            raise ValueError("attention operands need dense [H, D] inner dims (BLHD layout)")
+    if out is None:
+        out = torch.empty((B, Lq, H, D), dtype=q.dtype, device=q.device)
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    if workspace is None:
+        lib = _lib.load()
+        lib.rtv_attn_split_workspace_bytes.restype = ctypes.c_size_t
+        lib.rtv_attn_split_workspace_bytes.argtypes = [ctypes.c_int] * 4
+        need = lib.rtv_attn_split_workspace_bytes(B, Lq, H, int(kv_splits))
+        workspace = torch.empty(max(need, 16) // 4, dtype=torch.float32, device=q.device)
+    k, v = k_cache[:, r0:], v_cache[:, r0:]
+    _lib.call("rtv_attn_fwd_split", _ptr(q), _ptr(k), _ptr(v), _ptr(out), B, Lq, n0, n1,
+              (r1 - r0) if n1 else 0, H, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+              out.stride(0), out.stride(1), float(scale), int(causal_block), int(q_offset), int(kv_splits), _ptr(workspace),
+              workspace.numel() * workspace.element_size(), _dt(q), _stream())
+    return out
+
+
 # --------------------------------------------------------------------------------------- GEMM
 _gemm_ws = {}
 

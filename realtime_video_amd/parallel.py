@@ -64,7 +64,7 @@ class Pending:
 
 
 class ContextParallel(_ExchangeChoice):
-    def __init__(self, group=None, exchange="auto", overlap=True):
+    def __init__(self, group=None, exchange="auto", overlap=True, attn_kv_splits=1):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
@@ -76,6 +76,11 @@ class ContextParallel(_ExchangeChoice):
         # q all-to-all runs under the k|v projection (head exchange) and the K/V all-gather under the q projection (row
         # exchange); False = every collective completes before the next kernel is issued (A/B, debugging)
         self.overlap = overlap
+        # > 1: a rank's dense self-attention launch (world x fewer workgroups than the unsharded one: 95 at 8 ranks) is cut along
+        # the keys into this many ranges merged by a second kernel (rtv_attn_fwd_split).  Off by default: with one range the
+        # sharded forward is bit-identical with the unsharded one (what the tests assert); with more it differs by fp32
+        # summation order.
+        self.attn_kv_splits = int(attn_kv_splits)
 
     def shard(self, M):
         return shard_rows(M, self.world, self.rank)
@@ -195,9 +200,10 @@ class SimulatedContextParallel(_ExchangeChoice):
     kernels write straight into the shared cache / head buffer, so the collectives are no-ops.  Exercises the
     sharded launch geometry (row offsets, per-frame lookups, cache row placement) of the phase API."""
 
-    def __init__(self, world, exchange="auto"):
+    def __init__(self, world, exchange="auto", attn_kv_splits=1):
         self.world, self.rank = world, 0
         self.exchange = exchange
+        self.attn_kv_splits = int(attn_kv_splits)
 
     def shard(self, M):
         return shard_rows(M, self.world, 0)

@@ -494,6 +494,46 @@ def test_attention_duplicate_key_equals_repeated_keys(ops, Lq, n_real, total, H)
         ops.attn_fwd_dup(q, k, v, n_real + 1, 3)             # dup_key outside the window
 
 
+@pytest.mark.parametrize("Lq,Lkv,H,splits,waves", [(4680, 2048, 5, 2, 0), (1100, 3000, 16, 2, 0), (585, 9360, 8, 3, 0), (300, 1000, 5, 4, 4),
+                                                   (257, 700, 3, 16, 8), (33, 100, 1, 5, 0), (600, 1500, 2, 2, 82)])
+def test_attention_kv_split_matches_unsplit(ops, Lq, Lkv, H, splits, waves):
+    """rtv_attn_fwd_split (the self-attention launch of a context-parallel rank, xdit_context_parallel.py:179 in the reference):
+    key window cut into `splits` ranges of 64-key tiles, one workgroup per (head, query tile, range), unnormalised fp32 partials
+    merged by a second kernel.  Same mathematics as one launch, other fp32 summation order: both within the attention tolerance
+    of the fp32 definition and within 2 bf16 ulps of each other; through both kernels (4-wave / 8-wave lockstep, four-phase),
+    with a two-range ring window, more splits than key tiles, and splits = 1 (bit-identical with the plain launch)."""
+    q = _randn(1, Lq, H, 128, seed=1)
+    kc = _randn(1, Lkv + 200, H, 128, seed=2)
+    vc = _randn(1, Lkv + 200, H, 128, seed=3)
+    ops.attn_set_waves(waves)
+    try:
+        for seg0, seg1 in (((7, Lkv), (0, 0)), ((150, Lkv - 90), (20, 90))):
+            whole = ops.attn_fwd_win(q, kc, vc, seg0, seg1)
+            split = ops.attn_fwd_split(q, kc, vc, seg0, seg1, kv_splits=splits)
+            one = ops.attn_fwd_split(q, kc, vc, seg0, seg1, kv_splits=1)
+            kk = torch.cat([kc[:, seg0[0]:seg0[0] + seg0[1]], kc[:, seg1[0]:seg1[0] + seg1[1]]], 1).contiguous()
+            vv = torch.cat([vc[:, seg0[0]:seg0[0] + seg0[1]], vc[:, seg1[0]:seg1[0] + seg1[1]]], 1).contiguous()
+            ref = _attn_ref(q, kk, vv)
+            assert torch.equal(one, whole)
+            assert torch.isfinite(split.float()).all()
+            assert max_abs(whole, ref) <= 2e-2 and max_abs(split, ref) <= 2e-2
+            assert rel_l2(split, whole) <= 3e-3
+            assert max_abs(split, whole) <= 2 ** -7 * float(ref.abs().max())       # 2 ulps of bf16 at the largest magnitude
+        # block-causal window (the recompute pass): every workgroup splits its own tile count; rows whose keys inside a range
+        # are all masked contribute (m, l, O) = (-1e30, 0, 0)
+        Lc = min(Lq, Lkv)
+        cb = max(64, (Lc + 2) // 3)
+        qc, kq, vq = q[:, :Lc].contiguous(), kc[:, :Lc].contiguous(), vc[:, :Lc].contiguous()
+        whole = ops.attn_fwd(qc, kq, vq, causal_block=cb, q_offset=0)
+        split = ops.attn_fwd_split(qc, kq, vq, (0, Lc), kv_splits=splits, causal_block=cb, q_offset=0)
+        assert torch.isfinite(split.float()).all()
+        assert rel_l2(split, whole) <= 3e-3 and max_abs(split, whole) <= 2 ** -7 * float(whole.float().abs().max())
+    finally:
+        ops.attn_set_waves(0)
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd_split(q, kc, vc, (0, Lkv), kv_splits=2, workspace=torch.empty(16, dtype=torch.float32, device=DEV))
+
+
 def test_idle_wave_loops_change_nothing_but_the_time(ops):
     """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
     only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
