@@ -150,6 +150,19 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     case 5:
     case 50:
       return launch_gemm8(p, f16, true, stream);    // + split-K of the tail round = the default for large problems
+    case 8:
+      return launch_gemm4(p, f16, stream);          // 256x256, one wave per SIMD (lab: no split-K yet)
+    case 81:
+    case 82:
+    case 83:
+    case 84:
+    case 85:
+    case 86:
+    case 87:
+    case 89:
+    case 90:
+    case 91:
+      return launch_gemm4(p, f16, stream, tile_cfg - 80);   // timing experiments (garbage results)
     case 6:
       return launch_gemm8m(p, f16, false, stream);  // 128x256 ping-pong kernel (few-row problems), no split-K
     case 7:

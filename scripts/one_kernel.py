@@ -13,12 +13,15 @@ which = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = "cuda"
 M, d, H = 4680, 5120, 40
-if which == "gemm":          # FFN-in: 4680 x 13824 x 5120, bias + GELU(tanh) epilogue
-    a = torch.randn(M, d, device=dev).to(torch.bfloat16)
-    w = (torch.randn(13824, d, device=dev) * d ** -0.5).to(torch.bfloat16)
-    b = torch.randn(13824, device=dev).to(torch.bfloat16)
-    out = torch.empty(M, 13824, device=dev, dtype=torch.bfloat16)
-    fn = lambda: ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH, out=out)
+if which == "gemm":          # FFN-in: 4680 x 13824 x 5120, bias + GELU(tanh) epilogue (RTV_GEMM_MN=rows,cols: another problem)
+    gm, gn = (int(x) for x in os.environ.get("RTV_GEMM_MN", f"{M},13824").split(","))
+    a = torch.randn(gm, d, device=dev).to(torch.bfloat16)
+    w = (torch.randn(gn, d, device=dev) * d ** -0.5).to(torch.bfloat16)
+    b = torch.randn(gn, device=dev).to(torch.bfloat16)
+    out = torch.empty(gm, gn, device=dev, dtype=torch.bfloat16)
+    gemm_cfg = int(os.environ.get("RTV_GEMM_CFG", "0"))   # tile config under test (0 = default dispatch)
+    ops.ensure_gemm_workspace(torch.device(dev))
+    fn = lambda: ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH, out=out, tile_cfg=gemm_cfg)
 elif which == "attn":        # denoise-step self-attention: 4680 queries x 9360 cached keys x 40 heads
     q = torch.randn(1, M, H, 128, device=dev).to(torch.bfloat16)
     k = torch.randn(1, 2 * M, H, 128, device=dev).to(torch.bfloat16)

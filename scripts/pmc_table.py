@@ -9,7 +9,7 @@ import sqlite3
 import sys
 
 root = sys.argv[1]
-ROCM_KERNELS = {"gemm": "gemm8_kernel", "attn": "attn_fwd%_kernel", "conv": "conv_%_kernel", "layernorm": "layernorm_modulate_kernel",
+ROCM_KERNELS = {"gemm": "gemm%_kernel", "attn": "attn_fwd%_kernel", "conv": "conv_%_kernel", "layernorm": "layernorm_modulate_kernel",
                 "rope": "qk_norm_rope_cache_kernel"}   # SQL LIKE patterns (conv: conv_halo_kernel / conv_igemm_kernel, attn: lockstep / four-phase)
 
 

@@ -534,6 +534,19 @@ def test_attention_kv_split_matches_unsplit(ops, Lq, Lkv, H, splits, waves):
         ops.attn_fwd_split(q, kc, vc, (0, Lkv), kv_splits=2, workspace=torch.empty(16, dtype=torch.float32, device=DEV))
 
 
+def test_gemm_one_wave_per_simd_config_is_bit_identical(ops):
+    """Tile config 8 (gemm4.hip: four waves, 128 x 128 per wave, A by LDS DMA, W through registers) against the production
+    ping-pong kernel (config 4) on the layer shapes and ragged ones: same K order per accumulator, same epilogue - bit-identical;
+    K must be a multiple of 128 (the K loop runs in pairs of tiles)."""
+    for M, N, K, act in ((4680, 5120, 1024, 1), (585, 1536, 5120, 0), (300, 520, 256, 2), (257, 264, 128, 0), (1000, 2048, 1664, 1)):
+        a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+        r = _randn(M, N, seed=4)
+        assert torch.equal(ops.gemm(a, w, bias=b, act=act, tile_cfg=8), ops.gemm(a, w, bias=b, act=act, tile_cfg=4)), (M, N, K)
+        assert torch.equal(ops.gemm(a, w, bias=b, residual=r, tile_cfg=8), ops.gemm(a, w, bias=b, residual=r, tile_cfg=4)), (M, N, K)
+    with pytest.raises(RuntimeError):
+        ops.gemm(_randn(64, 192, seed=1), _randn(64, 192, seed=2), tile_cfg=8)
+
+
 def test_idle_wave_loops_change_nothing_but_the_time(ops):
     """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
     only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
