@@ -150,8 +150,8 @@ def main():
                          "rows = K/V all-gather (replicated cache); auto = heads when the head count divides")
     ap.add_argument("--cp-attn-splits", type=int, default=0,
                     help="context parallel: cut every rank's self-attention launch along the keys into this many ranges "
-                         "(rtv_attn_fwd_split; 1 = one launch, bit-identical with the unsharded forward; 0 = 2 when a rank's "
-                         "launch has fewer than 128 workgroups - 8 ranks of the 14B model: 95 - else 1)")
+                         "(rtv_attn_fwd_split; 1 = one launch, bit-identical with the unsharded forward; 0 = the count that "
+                         "fills the 256 CUs best for this rank count: 14B: 2 / 4 / 2 at 2 / 4 / 8 ranks)")
     ap.add_argument("--no-cp-overlap", action="store_true",
                     help="A/B: complete every context-parallel collective before the next kernel is issued (default: the "
                          "q all-to-all runs under the k|v projection / the K/V all-gather under the q projection)")
@@ -219,8 +219,13 @@ def main():
         model.enable_fp8()
     use_cp = world > 1 and args.parallel == "cp"
     cp_world = world if use_cp else max(1, args.simulate_cp)
-    if args.cp_attn_splits <= 0:   # workgroups of one rank's launch: heads x 256-row query tiles / ranks (either exchange)
-        args.cp_attn_splits = 2 if cp_world > 1 and mc["num_heads"] * 19 // cp_world < 128 else 1
+    if args.cp_attn_splits <= 0:
+        # workgroups of one rank's launch: heads x 256-row query tiles / ranks (either exchange), one per CU at a time: rounds of
+        # 256; S key ranges make S x as many workgroups of 1/S the length (+ ~6 % per extra range for the merge and the per-
+        # workgroup prologue: profiles/r03_attn_kv_split_ab.log).  2 ranks: 380 -> 2 rounds, S = 2 -> 3 half rounds; 8 ranks: 95 -> S = 2
+        g_wg = max(1, mc["num_heads"] * 19 // cp_world)
+        cost = {sp: -(-g_wg * sp // 256) / sp * (1 + 0.06 * (sp - 1)) for sp in (1, 2, 4) if sp <= cp_world}
+        args.cp_attn_splits = min(cost, key=lambda sp: (cost[sp], sp)) if cp_world > 1 else 1
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
         model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap,
