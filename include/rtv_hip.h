@@ -365,6 +365,14 @@ int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void*
                     void* out, int out_ld, int T, int H, int W, int Cin, int Cout, int kt, int kh, int kw,
                     int resample, int n_split, const void* zeros, int y_out0, int y_in0, int in_rows, int img_rows,
                     rtv_stream_t stream);
+/* The first conv of a ResidualBlock with the RMS_norm * gamma + SiLU behind it (wan/modules/vae.py:186-192) in its epilogue:
+ * out = SiLU(RMS_norm(conv3x3x3(in) + bias) * gamma), `in` = the causal concat buffer as for rtv_conv_cl.  Returns 1 - nothing
+ * launched, no error - when the layer is not one the halo-tile conv kernel takes with all channels of a pixel in one workgroup
+ * (Cout == 96, Cin % 32 == 0, not RTV_CONV_GATHER): run rtv_conv_cl + rtv_rmsnorm_silu_cl then.  rtv_conv_set_fuse_norm(0)
+ * switches the fusion off (A/B; the two forms differ by the fp32 summation order of the 96 squares). */
+int rtv_conv3_norm_silu_cl(const void* in, const void* w, const void* bias, const void* gamma, void* out, int out_ld,
+                           int T, int H, int W, int Cin, int Cout, int flags, const void* zeros, rtv_stream_t stream);
+int rtv_conv_set_fuse_norm(int on);
 /* RMS_norm over channels (+SiLU) on channels-last pixels (wan/modules/vae.py:39-54): C in {96,192,384}. */
 int rtv_rmsnorm_silu_cl(const void* x, void* out, const void* gamma, int C, int64_t npix, int apply_silu,
                         rtv_stream_t stream);

@@ -42,6 +42,8 @@ struct ConvParams {
                      // is image row y_in0 (in input resolution); limH is then the IMAGE height
   int in_rows;       // rows held by the input buffer
   int gather;       // 1: keep a 3x3x3 stride-1 conv on the gather kernel (RTV_CONV_GATHER)
+  const uint16_t* norm_gamma;  // halo kernel, Cout == 96, no residual: the epilogue writes SiLU(RMS_norm(conv + bias) * gamma)
+                               // (wan/modules/vae.py:39-54 + the nn.SiLU behind it, :186-192) instead of conv + bias
   int n_split;      // >0: output channel n -> frame 2t + n / n_split, channel n % n_split
   int M;            // T*H*W
   int tiles_m, tiles_n;
@@ -523,12 +525,17 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
   CH_FENCE();
 #undef CH_FENCE
 
-  // ---- epilogue: bias (+ residual) through a wave-private 64 x 96 image (rows of 192 bytes), 16 contiguous bytes per lane
+  // ---- epilogue: bias (+ residual) through a wave-private 64 x 96 image (rows of 192 bytes), 16 contiguous bytes per lane.
+  //      Fused RMS_norm + SiLU (p.norm_gamma, 96 filters = the whole channel axis of a pixel in this workgroup): lane (l31, gl)
+  //      holds 48 of pixel l31's 96 outputs, lane + 32 the other 48 - sum of squares in the lane, one exchange, then
+  //      SiLU(y * sqrt(96) / max(|y|, 1e-12) * gamma) on the fp16-rounded y, the arithmetic of rmsnorm_silu_cl_kernel.
   constexpr int TM = 2, TN = 3, CPR = TN * 4;
   char* img = smem + wave * (TM * 32 * TN * 64);
 #pragma unroll
   for (int mi = 0; mi < TM; ++mi) {
     const int row = mi * 32 + l31;
+    float yv[TN][4][4];
+    float ssq = 0.f;
 #pragma unroll
     for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
@@ -545,8 +552,35 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
         u32x2 o;
         o[0] = pack_f16x2(v[0], v[1]);
         o[1] = pack_f16x2(v[2], v[3]);
-        *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gl)) = o;
+        if (p.norm_gamma) {
+          unpack_f16x2(o[0], yv[ni][rq][0], yv[ni][rq][1]);   // the conv output as the unfused path stores it
+          unpack_f16x2(o[1], yv[ni][rq][2], yv[ni][rq][3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ssq += yv[ni][rq][i] * yv[ni][rq][i];
+        } else {
+          *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gl)) = o;
+        }
       }
+    if (p.norm_gamma) {
+      ssq += __shfl_xor(ssq, 32, 64);
+      const float inv = sqrtf(96.f) / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const u32x2 gg = *(const u32x2*)(p.norm_gamma + ni * 32 + rq * 8 + gl * 4);
+          float g4[4];
+          unpack_f16x2(gg[0], g4[0], g4[1]);
+          unpack_f16x2(gg[1], g4[2], g4[3]);
+          float z[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[i] = silu(yv[ni][rq][i] * inv * g4[i]);
+          u32x2 o;
+          o[0] = pack_f16x2(z[0], z[1]);
+          o[1] = pack_f16x2(z[2], z[3]);
+          *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gl)) = o;
+        }
+    }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
@@ -622,6 +656,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
                     p.limW == p.inW && p.Cin % 32 == 0 && p.Cin <= 384 && p.Cout % 96 == 0 && p.Cout <= 384 &&
                     !((p.out_ld | (p.residual ? p.res_ld : 0)) & 7) && !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15) &&
                     (size_t)(p.T + 2) * p.inH * p.inW * p.Cin < 0x7fffffffull;
+  if (p.norm_gamma && !(halo && p.Cout == 96 && !p.residual && !((uintptr_t)p.norm_gamma & 7)))
+    return set_error(-1, "conv: the fused RMS_norm + SiLU epilogue needs a halo-kernel layer with 96 filters and no residual");
   if (halo) return launch_conv_halo(p, stream);
   if (p.Cout % 96 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 96, 32, 2, 1>(p, stream);
   if (p.Cout <= 32) return launch_conv_cfg<128, 32, 32, 2, 1>(p, stream);
@@ -651,6 +687,54 @@ extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, cons
                            int resample, int n_split, const void* zeros, rtv_stream_t stream) {
   return rtv_conv_cl_win(in, w, bias, residual, res_ld, out, out_ld, T, H, W, Cin, Cout, kt, kh, kw, resample, n_split,
                          zeros, 0, 0, -1, -1, stream);
+}
+
+static bool g_conv_fuse_norm = true;   // rtv_conv_set_fuse_norm(0): A/B against the separate rmsnorm_silu pass (tests)
+extern "C" int rtv_conv_set_fuse_norm(int on) {
+  g_conv_fuse_norm = on != 0;
+  return 0;
+}
+
+/* 3x3x3 causal conv (input = the concat buffer, as rtv_conv_cl with kt = kh = kw = 3) whose epilogue applies the RMS_norm * gamma
+ * + SiLU that follows it in a ResidualBlock (wan/modules/vae.py:186-192): out = SiLU(RMS_norm(conv + bias) * gamma).
+ * Returns 1 (nothing launched, no error) when the layer is not one the halo-tile kernel takes with all 96 channels of a pixel in
+ * one workgroup - the caller then runs the conv and rtv_rmsnorm_silu_cl separately. */
+extern "C" int rtv_conv3_norm_silu_cl(const void* in, const void* w, const void* bias, const void* gamma, void* out, int out_ld,
+                                      int T, int H, int W, int Cin, int Cout, int flags, const void* zeros, rtv_stream_t stream) {
+  if (!in || !w || !out || !zeros || !gamma) return set_error(-1, "conv: null pointer");
+  if (!g_conv_fuse_norm || !g_conv_halo || (flags & RTV_CONV_GATHER) || Cout != 96 || Cin % 32 || Cin > 384 || (out_ld & 7) ||
+      ((uintptr_t)out & 15) || ((uintptr_t)gamma & 7) || (size_t)(T + 2) * H * W * Cin >= 0x7fffffffull)
+    return 1;
+  ConvParams p;
+  p.in = (const uint16_t*)in;
+  p.w = (const uint16_t*)w;
+  p.out = (uint16_t*)out;
+  p.bias = (const uint16_t*)bias;
+  p.residual = nullptr;
+  p.zeros = (const uint16_t*)zeros;
+  p.out_ld = out_ld;
+  p.res_ld = 0;
+  p.T = T;
+  p.H = H;
+  p.W = W;
+  p.inH = H;
+  p.inW = W;
+  p.sy = p.st = 1;
+  p.pad_h = p.pad_w = 1;
+  p.limH = H;
+  p.limW = W;
+  p.y_out0 = p.y_in0 = 0;
+  p.in_rows = H;
+  p.gather = 0;
+  p.norm_gamma = (const uint16_t*)gamma;
+  p.Cin = Cin;
+  p.Cout = Cout;
+  p.kt = p.kh = p.kw = 3;
+  p.ups = 0;
+  p.n_split = 0;
+  p.M = T * H * W;
+  p.tiles_m = p.tiles_n = 0;
+  return launch_conv(p, (hipStream_t)stream);
 }
 
 extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
@@ -707,6 +791,7 @@ extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, 
     p.limH = img_rows;
   }
   p.gather = gather;
+  p.norm_gamma = nullptr;
   p.Cin = Cin;
   p.Cout = Cout;
   p.kt = kt;

@@ -383,6 +383,7 @@ struct Ctx {
 };
 
 // conv over concat buffer `ci` whose slices [2, 2+T) already hold the new input; then roll the cache.
+static int roll_cache(Ctx& c, int ci, int T, int H, int W, int Cin);
 static int cached_conv3(Ctx& c, int ci, int T, int H, int W, int Cin, const rtv_vae_conv& cw, int Cout,
                         const void* residual, void* out, int out_ld) {
   uint16_t* buf = c.cat(ci);
@@ -390,6 +391,12 @@ static int cached_conv3(Ctx& c, int ci, int T, int H, int W, int Cin, const rtv_
   // the gather kernel - 16 halo tiles per frame cannot fill the chip (scripts/conv_bench.py: 315 vs 399 TF/s at 60 x 104)
   RTV_TRY(rtv_conv_cl(buf, cw.w, cw.b, residual, Cout, out, out_ld, T, H, W, Cin, Cout, 3, 3, 3,
                       W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE, 0, c.zeros(), c.stream));
+  return roll_cache(c, ci, T, H, W, Cin);
+}
+
+// the causal conv's feature cache: the last two input slices move to the front of the concat buffer (vae.py:17-36)
+static int roll_cache(Ctx& c, int ci, int T, int H, int W, int Cin) {
+  uint16_t* buf = c.cat(ci);
   const size_t slice = (size_t)H * W * Cin * 2;
   char* b = (char*)buf;
   if (T == 1) {
@@ -409,8 +416,20 @@ static int res_block(Ctx& c, int ci, int T, int H, int W, int cin, int cout, con
   const int64_t npix = (int64_t)T * H * W;
   const size_t sl_in = (size_t)H * W * cin, sl_out = (size_t)H * W * cout;
   RTV_TRY(rtv_rmsnorm_silu_cl(x, c.cat(ci) + 2 * sl_in, rw.gamma0, cin, npix, 1, c.stream));
-  RTV_TRY(cached_conv3(c, ci, T, H, W, cin, rw.conv_a, cout, nullptr, tmp, cout));
-  RTV_TRY(rtv_rmsnorm_silu_cl(tmp, c.cat(ci + 1) + 2 * sl_out, rw.gamma3, cout, npix, 1, c.stream));
+  // conv_a -> RMS_norm -> SiLU: one launch where the conv kernel holds all channels of a pixel (96 filters, halo kernel), with
+  // the normalised activation written straight into conv_b's concat buffer; else conv into `tmp` + the separate pass
+  {
+    int st = cout == 96 ? rtv_conv3_norm_silu_cl(c.cat(ci), rw.conv_a.w, rw.conv_a.b, rw.gamma3, c.cat(ci + 1) + 2 * sl_out, cout, T, H,
+                                                  W, cin, cout, W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE, c.zeros(), c.stream)
+                        : 1;
+    if (st < 0) return st;
+    if (st == 0) {
+      RTV_TRY(roll_cache(c, ci, T, H, W, cin));
+    } else {
+      RTV_TRY(cached_conv3(c, ci, T, H, W, cin, rw.conv_a, cout, nullptr, tmp, cout));
+      RTV_TRY(rtv_rmsnorm_silu_cl(tmp, c.cat(ci + 1) + 2 * sl_out, rw.gamma3, cout, npix, 1, c.stream));
+    }
+  }
   const uint16_t* hres = x;
   if (rw.shortcut.w) {  // 1x1x1 conv = plain GEMM over pixels (K = 96 is not a multiple of the GEMM's 64: conv kernel)
     if (cin % 64 == 0)

@@ -40,6 +40,8 @@ class _VaeWeights(ctypes.Structure):
 _lib.EXTRA_SIGNATURES.update({
     "rtv_conv_cl": [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int] + [ctypes.c_int] * 10 + [c_vp, c_vp],
     "rtv_rmsnorm_silu_cl": [c_vp, c_vp, c_vp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_vp],
+    "rtv_conv3_norm_silu_cl": [c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_int] + [ctypes.c_int] * 6 + [c_vp, c_vp],
+    "rtv_conv_set_fuse_norm": [ctypes.c_int],
     "rtv_softmax_rows": [c_vp, ctypes.c_int, c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp],
     "rtv_vae_decode": [ctypes.POINTER(_VaeWeights), c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                        c_vp, ctypes.c_size_t, c_vp, c_vp],

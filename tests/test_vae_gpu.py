@@ -109,6 +109,53 @@ def test_upsample_conv2d_and_time_conv():
     assert out.shape == y.shape and max_abs(out, y) <= 1e-2
 
 
+@pytest.mark.parametrize("Cin,T,H,W", [(96, 2, 33, 70), (192, 1, 16, 32), (96, 4, 48, 64), (384, 1, 5, 9)])
+def test_conv_with_fused_rmsnorm_silu_epilogue(Cin, T, H, W):
+    """rtv_conv3_norm_silu_cl: the first conv of a ResidualBlock with the RMS_norm * gamma + SiLU behind it
+    (wan/modules/vae.py:39-54, :186-192) in the halo kernel's epilogue (96 filters = all channels of a pixel in one workgroup).
+    Against the two separate launches on the same input: same arithmetic on the fp16-rounded conv output, only the fp32 order of
+    the 96 squares differs - isolated one-ulp fp16 differences; against torch fp32; repeated launches bit-identical; layers the
+    kernel does not take (192 filters, RTV_CONV_GATHER) return 1 and launch nothing."""
+    from realtime_video_amd import _lib
+    from realtime_video_amd.vae_decoder import pack_conv_weight
+    Cout = 96
+    g = torch.Generator().manual_seed(Cin + T + H)
+    x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.7).half().to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
+    b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
+    gamma = (1.0 + 0.2 * torch.randn(Cout, generator=g)).half().to(DEV)
+    wp = pack_conv_weight(w).to(DEV)
+    zeros = torch.zeros(64, dtype=torch.float16, device=DEV)
+    lib = _lib.load()
+
+    def fused(flags=0, cout=Cout, weight=wp):
+        out = torch.full((T, H, W, cout), float("nan"), dtype=torch.float16, device=DEV)
+        fn = lib.rtv_conv3_norm_silu_cl
+        fn.argtypes = _lib.EXTRA_SIGNATURES["rtv_conv3_norm_silu_cl"]
+        st = fn(_p(x), _p(weight), _p(b), _p(gamma), _p(out), cout, T, H, W, Cin, cout, flags, _p(zeros), _stream())
+        return st, out
+
+    conv = _conv_cl(x, w, b, T, H, W, 3, 3, 3)
+    sep = torch.empty_like(conv)
+    _lib.call("rtv_rmsnorm_silu_cl", _p(conv), _p(sep), _p(gamma), Cout, T * H * W, 1, _stream())
+    st, a = fused()
+    assert st == 0
+    st, a2 = fused()
+    assert st == 0 and torch.equal(a, a2) and torch.isfinite(a.float()).all()
+    assert float((a != sep).float().mean()) <= 2e-3 and max_abs(a, sep) <= 4e-3
+    xin = x.permute(3, 0, 1, 2).unsqueeze(0).float()
+    y = F.conv3d(F.pad(xin, (1, 1, 1, 1, 0, 0)), w.float(), b.float())[0].permute(1, 2, 3, 0)
+    ref = F.silu(F.normalize(y, dim=-1) * Cout ** 0.5 * gamma.float())
+    assert max_abs(a, ref) <= 2e-2 and rel_l2(a, ref) <= 3e-3
+    st, untouched = fused(flags=16)                      # RTV_CONV_GATHER: not taken, nothing written
+    assert st == 1 and torch.isnan(untouched.float()).all()
+    _lib.call("rtv_conv_set_fuse_norm", 0)
+    try:
+        assert fused()[0] == 1
+    finally:
+        _lib.call("rtv_conv_set_fuse_norm", 1)
+
+
 @pytest.mark.parametrize("C", [96, 192, 384])
 def test_rmsnorm_silu_channels_last(C):
     from realtime_video_amd import _lib
@@ -135,6 +182,36 @@ def test_softmax_rows():
     _lib.call("rtv_softmax_rows", _p(s), n, _p(p), ldp, n, n, _stream())
     assert max_abs(p[:, :n], torch.softmax(s.float(), -1)) <= 1e-3
     assert float(p[:, n:].abs().max()) == 0
+
+
+def test_decoder_fused_norm_epilogue_vs_separate_pass():
+    """The decoder with the conv + RMS_norm + SiLU fusion of the 96-channel ResidualBlocks (default) against the same decoder with
+    the separate normalisation pass (rtv_conv_set_fuse_norm(0)): two streamed blocks at a small latent, pixels within 2e-3 of each
+    other, mean difference below one fp16 ulp (the two forms differ by the fp32 summation order of a pixel's 96 squares: isolated
+    one-ulp differences of the normalised activations, carried through the remaining layers)."""
+    from oracle import vae_oracle as vo
+    from realtime_video_amd import _lib
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapper
+    g = torch.Generator().manual_seed(5)
+    zs = [torch.randn(1, 3, 16, 12, 20, generator=g).half().to(DEV) for _ in range(2)]
+    outs = []
+    for fuse in (1, 0):
+        _lib.call("rtv_conv_set_fuse_norm", fuse)
+        try:
+            dec = VAEDecoderWrapper(DEV)
+            dec.load_state_dict(vo.make_vae_weights(seed=0))
+            cache = [None] * 55
+            px = []
+            for z in zs:
+                p, cache = dec(z, *cache)
+                px.append(p.clone())
+            outs.append(px)
+        finally:
+            _lib.call("rtv_conv_set_fuse_norm", 1)
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert max_abs(a, b) <= 2e-3 and float((a - b).abs().mean()) <= 3e-4      # (fp16 pixels: one ulp is 2.4e-4 .. 4.9e-4)
+    assert not all(torch.equal(a, b) for a, b in zip(*outs))      # the fused path really ran
 
 
 def test_streaming_decoder_matches_reference_golden(golden):
