@@ -125,9 +125,18 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     // shards of context parallelism: 585 rows = 3 x 256 wastes 24 %, 5 x 128 8.6 %) - the 128x128 kernel (2 workgroups per
     // CU) otherwise.  Thresholds from profiles/r01_kbench_*, profiles/r02_gemm_shapes_*.
     const long tiles_n = (p.N + 255) / 256;
-    const long tiles256 = (long)((p.M + 255) / 256) * tiles_n, tiles128 = (long)((p.M + 127) / 128) * tiles_n;
-    const long pad256 = (long)((p.M + 255) / 256) * 256, pad128 = (long)((p.M + 127) / 128) * 128;
-    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < pad256 * 93 || tiles256 < 160))
+    const long rt256 = (p.M + 255) / 256, rt128 = (p.M + 127) / 128;
+    const long tiles256 = rt256 * tiles_n, tiles128 = rt128 * tiles_n;
+    // rows the kernels really multiply: gemm8's waves whose 128 rows lie beyond M run the idle loop (the upper half of the last
+    // row of tiles costs barriers and DMA duty only), so 585 rows are 640 for both kernels
+    const long last256 = p.M - (rt256 - 1) * 256;
+    const long eff256 = (rt256 - 1) * 256 + (last256 <= 128 ? 128 : 256), pad128 = rt128 * 128;
+    // a SMALL tail round behind one to three full rounds of 256x256 tiles (300 = 256 + 44, 540 = 2 x 256 + 28) keeps the chip
+    // waiting for a few split-K units; the same problem in 128-row tiles has a well filled tail (r03: M = 1170 / 2340 / 3120,
+    // profiles/r03_gemm_small_m_dispatch.log: 6-26 %)
+    const long tail256 = tiles256 % 256;
+    const bool small_tail = tiles256 > 256 && tiles256 < 4 * 256 && tail256 != 0 && tail256 * 4 < 256;
+    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < eff256 * 93 || tiles256 < 160 || small_tail))
       return launch_gemm8m(p, f16, true, stream);
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
     // along K over the idle CUs, scripts/cp_gemm_shapes.py)
