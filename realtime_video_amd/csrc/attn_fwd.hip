@@ -796,31 +796,31 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
       }
       // exponentials of the first 32-key block here; those of the second block run inside the PV phase, between the
       // MFMAs of the first block (the wave's own issue slots while the matrix pipe works)
-      static_for<0, 8>([&](auto ic) { exp_step(IntC<0>{}, ic); });
+      static_for<0, 4>([&](auto ic) { exp_step(IntC<0>{}, ic); });
     }
-    // the first half of P^T is complete HERE: without this the compiler sinks exponentials / packs below the barrier, into
-    // the matrix phase (sched_barrier does not stop its code sinking)
-    asm volatile("" : "+v"(pf[0][0]), "+v"(pf[0][1]), "+v"(ps2));
+    // the first QUARTER of P^T (keys 0-15: what the first four PV MFMAs multiply) is complete HERE: without this the compiler
+    // sinks exponentials / packs below the barrier, into the matrix phase (sched_barrier does not stop its code sinking)
+    asm volatile("" : "+v"(pf[0][0]), "+v"(ps2));
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // V(j+1) has landed
     ATT_STAMP8(5);
     PP_BARRIER();
     // ---------------- PV: O^T += V^T . P^T (four independent accumulator chains)
     ATT_STAMP8(6);
     lds_wait_frags(frag);
-    // first 32-key block: 8 MFMAs, one step of the second block's exponentials behind each
-    static_for<0, 8>([&](auto ic) {
-      constexpr int i = decltype(ic)::value, s_ = i >> 2, db = i & 3;
-      oacc[db] = mfma32<F16>(frag[s_ * 4 + db], pf[0][s_], oacc[db]);
-      exp_step(IntC<1>{}, ic);
+    // 16 MFMAs in the order (key block, 16-key step, dim block); behind MFMA i (i < 12) one step of the exponentials that are
+    // still missing - keys 16-31 of the first block behind MFMAs 0-3 (needed from MFMA 4 on), the second block behind MFMAs 4-11
+    // (needed from MFMA 8 / 12 on): the wave's own issue slots while the matrix pipe works
+    static_for<0, 16>([&](auto ic) {
+      constexpr int i = decltype(ic)::value, kbk = i >> 3, s_ = (i >> 2) & 1, db = i & 3;
+      oacc[db] = mfma32<F16>(frag[(kbk * 2 + s_) * 4 + db], pf[kbk][s_], oacc[db]);
+      if constexpr (i < 12) {
+        constexpr int f = i + 4;
+        exp_step(IntC<(f >> 3)>{}, IntC<(f & 7)>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     l_run += ps2[0] + ps2[1];
     ps2 = f32x2{0.f, 0.f};
-#pragma unroll
-    for (int s_ = 0; s_ < 2; ++s_) {
-#pragma unroll
-      for (int db = 0; db < 4; ++db) oacc[db] = mfma32<F16>(frag[(2 + s_) * 4 + db], pf[1][s_], oacc[db]);
-    }
     asm volatile("" : "+v"(l_run));
     ATT_STAMP8(7);
     PP_BARRIER();
