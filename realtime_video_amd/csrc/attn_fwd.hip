@@ -457,9 +457,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
 //         QK  16 MFMAs on register operands, S^T = K . Q^T; behind MFMA n the V^T fragment n of the tile is read (2 transpose
 //             reads) into the register MFMA n has just consumed - K and V^T fragments share one 64-register block, and the
 //             reads cost issue slots in the shadow of the matrix pipe instead of ~280 cycles in front of the softmax
-//         LV  issue the V DMA of tile j+2; mask, row maximum, lazy rescale, first half of the exponentials -> P^T (VALU beside
+//         LV  issue the V DMA of tile j+2; mask, row maximum, lazy rescale, first quarter of the exponentials -> P^T (VALU beside
 //             the partner's MFMAs)
-//         PV  16 MFMAs on register operands, O^T += V^T . P^T, the second half of the exponentials between the first eight
+//         PV  16 MFMAs on register operands, O^T += V^T . P^T, the other three quarters of the exponentials behind the first twelve
 //     waves 4-7 run ONE phase behind waves 0-3, so in every phase one wave of each SIMD is in a matrix phase and its
 //     partner in a load/VALU phase:
 //         phase 4j: g0 LK(j)  g1 PV(j-1) | 4j+1: g0 QK(j)  g1 LK(j) | 4j+2: g0 LV(j)  g1 QK(j) | 4j+3: g0 PV(j)  g1 LV(j)
@@ -794,8 +794,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
       }
-      // exponentials of the first 32-key block here; those of the second block run inside the PV phase, between the
-      // MFMAs of the first block (the wave's own issue slots while the matrix pipe works)
+      // exponentials of the first 16 keys here (what the first four PV MFMAs multiply); the others run inside the PV phase, one
+      // step behind each of its first twelve MFMAs (the wave's own issue slots while the matrix pipe works)
       static_for<0, 4>([&](auto ic) { exp_step(IntC<0>{}, ic); });
     }
     // the first QUARTER of P^T (keys 0-15: what the first four PV MFMAs multiply) is complete HERE: without this the compiler
