@@ -564,7 +564,7 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       }
     }
   }
-  *sp = SplitArgs{T, 1, nullptr, nullptr, 0};
+  *sp = SplitArgs{T, 1, nullptr, nullptr, 0, 0};
   *grid = T;
   const int R = T % G;
   if (allow_split && slabs && R > 0) {   // T < G (small M under context parallelism): every tile is a split tile
@@ -577,6 +577,10 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       sp->slabs = slabs;
       sp->counters = counters;
       sp->tail_tiles = R;
+      // a FEW split units (ffn-in at M = 4680: 1026 tiles = 4 rounds + 2 tiles -> 16 units) go first: behind the last full round
+      // they are a fifth round on 16 of 256 CUs plus its publish / reduce; in front they run beside the first full tiles
+      // (-3 % on that shape; with many units - 232 of the QKV projection - the order of round 2 stays: +3 % the other way)
+      sp->split_first = (R * S * 4 <= G) ? 1 : 0;
       *grid = (T - R) + R * S;
     }
   }

@@ -20,6 +20,7 @@ struct SplitArgs {
   int* counters;    // [split tiles]: zero between launches (zeroed when the workspace is attached; the reducer of a
                     // tile puts its counter back to zero)
   int tail_tiles;   // R: number of split tiles (block ids first_unit .. first_unit + R * S)
+  int split_first;  // 1: the split units get the lowest block ids (dispatched first): chosen when there are few of them
 };
 
 // host: decide the split for T tiles of nk K-tiles each (defined in gemm8.hip, which owns the workspace pointers).
@@ -36,6 +37,10 @@ __device__ __forceinline__ bool split_unit_of_block(const SplitArgs& sp, int bid
                                                     int* seg, int* kt_begin, int* kt_end) {
   *seg = 0;
   *unit = -1;
+  if (sp.split_first) {
+    const int nsu = sp.tail_tiles * sp.S;
+    bid = bid < nsu ? sp.first_unit + bid : bid - nsu;
+  }
   if (bid < sp.first_unit) {
     *tile_id = xcd_remap(bid, sp.first_unit);
   } else {
