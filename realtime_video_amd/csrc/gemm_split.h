@@ -4,7 +4,8 @@
 // occupancy for a whole tile time.  Instead each of them is cut along K into S segments ("units", S = min(8, G/R)),
 // so the tail round runs R*S workgroups for 1/S of a tile time (with T < G every tile is a tail tile).  Partial accumulators go to an fp32 slab in a
 // caller-provided workspace (rtv_gemm_set_workspace); the last arriver of a tile (agent-scope release / acquire around
-// an arrival counter, no spinning) adds the other slabs to its registers, resets the counter and runs the fused epilogue.
+// an arrival counter, no spinning) sums the slabs in a FIXED order (arrival order never shows in the result), resets the
+// counter and runs the fused epilogue.
 #pragma once
 #include "rtv_common.h"
 
@@ -94,8 +95,18 @@ __device__ __forceinline__ bool split_k_reduce(f32x16 (&acc)[TM][2], const Split
   }
   __syncthreads();
   const int unit0 = unit - seg;
+  // The order of the sum must not depend on WHICH unit arrived last (fp32 addition is not associative; a context-parallel rank on
+  // another GPU, or the same launch tomorrow, sees another arrival order).  S == 2: own + other is the same number either way.
+  // S > 2: this unit's own slab is in memory as well (it was published before the ticket was drawn), so the reducer starts from
+  // zero and adds all S slabs in index order.
+  if (sp.S > 2) {
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[blk >> 1][blk & 1][r] = 0.f;
+  }
   for (int s = 0; s < sp.S; ++s) {
-    if (s == seg) continue;
+    if (s == seg && sp.S == 2) continue;
     const float4* other = (const float4*)(sp.slabs + (size_t)(unit0 + s) * SPLIT_SLAB_FLOATS);
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk)

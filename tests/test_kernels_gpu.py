@@ -547,6 +547,23 @@ def test_gemm_one_wave_per_simd_config_is_bit_identical(ops):
         ops.gemm(_randn(64, 192, seed=1), _randn(64, 192, seed=2), tile_cfg=8)
 
 
+def test_gemm_split_k_sum_order_is_fixed(ops):
+    """Split-K with more than two K segments per tile (few tiles on 256 CUs: S = 8): the reducer sums the published slabs in index
+    order whichever unit arrived last, so repeated launches - and the same GEMM on another rank / GPU - give the same bits.
+    40 launches each of three such problems (with an unrelated kernel in between to shuffle the arrival order)."""
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    for M, N, K, cfg in ((300, 520, 2048, 5), (585, 1536, 5120, 7), (4680, 512, 5120, 5)):
+        a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+        first = ops.gemm(a, w, bias=b, tile_cfg=cfg).clone()
+        noise = torch.empty(1 << 22, device=DEV)
+        for i in range(40):
+            if i % 3 == 0:
+                noise.normal_()
+            assert torch.equal(ops.gemm(a, w, bias=b, tile_cfg=cfg), first), (M, N, K, i)
+        ref = (a.float() @ w.float().t() + b.float())
+        assert rel_l2(first, ref) <= 1e-2
+
+
 def test_idle_wave_loops_change_nothing_but_the_time(ops):
     """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
     only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
