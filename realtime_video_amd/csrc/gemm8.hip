@@ -51,9 +51,36 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 __device__ unsigned long long* g_timeline = nullptr;   // [grid][4]: realtime start, after K loop, end, (seg << 32 | tile)
 #endif
 
+// (the 128 x 256 body, defined below: gemm8_kernel runs the half-tile units of its tail round through it)
+template <bool F16>
+__device__ __forceinline__ void gemm8m_body(const GemmParams& p, const SplitArgs& sp, int m0, int n0, int tile_id, int seg, int unit,
+                                            int kt_begin, int kt_end, bool is_split);
+
 template <bool F16, bool SKIP_IDLE>
 __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
+  // ---- tail round as half tiles (sp.half_tail): block ids >= first_unit (after the split_first rotation) are 128 x 256 units
+  int bid0 = blockIdx.x;
+  if (sp.half_tail) {
+    const int nhu = 2 * sp.tail_tiles;
+    if (sp.split_first) bid0 = bid0 < nhu ? sp.first_unit + bid0 : bid0 - nhu;
+    if (bid0 >= sp.first_unit) {
+      const int v = xcd_remap(bid0 - sp.first_unit, nhu);   // the two halves of a tile side by side on one XCD (they share W)
+      const int tile_id = sp.first_unit + (v >> 1);
+      constexpr int GROUP_M = 8;
+      const int per_group = GROUP_M * p.tiles_n;
+      const int group = tile_id / per_group;
+      const int first_m = group * GROUP_M;
+      const int gm = min(p.tiles_m - first_m, GROUP_M);
+      const int in_group = tile_id - group * per_group;
+      const int m0h = (first_m + in_group % gm) * BM + (v & 1) * 128;
+      if (m0h >= p.M) return;                                // the lower half of a ragged last row of tiles has no rows
+      gemm8m_body<F16>(p, sp, m0h, (in_group / gm) * BN, tile_id, 0, -1, 0, p.K / BK, false);
+      return;
+    }
+    sp.S = 1;             // the full tiles below: plain mapping of bid0
+    sp.split_first = 0;
+  }
 #ifdef RTV_GEMM_TIMELINE
   const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long tl_t1 = 0;
@@ -70,7 +97,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   // ---- workgroup -> (tile, K segment)
   const int nk_total = p.K / BK;
   int tile_id, seg, unit, kt_begin, kt_end;
-  const bool is_split = split_unit_of_block(sp, blockIdx.x, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
+  const bool is_split = split_unit_of_block(sp, bid0, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
   // tile id -> (m, n): GROUP_M-row supertiles so concurrently running tiles share A / W panels in L2
   constexpr int GROUP_M = 8;
   const int per_group = GROUP_M * p.tiles_n;
@@ -308,6 +335,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 // waits with vmcnt(6) - everything but the pieces it has just issued - so each piece is in flight for two to three
 // intervals before the counted wait retires it, one barrier before its first reader.
 static bool g_gemm8_skip_idle = true;   // rtv_gemm_set_skip_idle(0): A/B (lab)
+static bool g_gemm8_half_tail = true;   // rtv_gemm_set_skip_idle(2 / 3): half-tile tail off / on (A/B)
 namespace g8m {
 constexpr int BM = 128, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
@@ -315,7 +343,8 @@ constexpr int LDS_BYTES = 9 * HALF_BYTES;    // 144 KiB: 3 buffers x {A, W rows 
 }  // namespace g8m
 
 template <bool F16>
-__global__ __launch_bounds__(g8::THREADS, 2) void gemm8m_kernel(GemmParams p, SplitArgs sp) {
+__device__ __forceinline__ void gemm8m_body(const GemmParams& p, const SplitArgs& sp, int m0, int n0, int tile_id, int seg, int unit,
+                                            int kt_begin, int kt_end, bool is_split) {
   using namespace g8m;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -323,18 +352,6 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8m_kernel(GemmParams p, Sp
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int l31 = lane & 31, g = lane >> 5;
-
-  const int nk_total = p.K / BK;
-  int tile_id, seg, unit, kt_begin, kt_end;
-  const bool is_split = split_unit_of_block(sp, blockIdx.x, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * p.tiles_n;
-  const int group = tile_id / per_group;
-  const int first_m = group * GROUP_M;
-  const int gm = min(p.tiles_m - first_m, GROUP_M);
-  const int in_group = tile_id - group * per_group;
-  const int m0 = (first_m + in_group % gm) * BM;
-  const int n0 = (in_group / gm) * BN;
 
   uint32_t src_off[3][2];  // [A, W0, W1][piece]: byte offsets at k = 0
   {
@@ -463,6 +480,21 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8m_kernel(GemmParams p, Sp
   }
 }
 
+template <bool F16>
+__global__ __launch_bounds__(g8::THREADS, 2) void gemm8m_kernel(GemmParams p, SplitArgs sp) {
+  using namespace g8m;
+  const int nk_total = p.K / BK;
+  int tile_id, seg, unit, kt_begin, kt_end;
+  const bool is_split = split_unit_of_block(sp, blockIdx.x, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = tile_id / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = tile_id - group * per_group;
+  gemm8m_body<F16>(p, sp, (first_m + in_group % gm) * BM, (in_group / gm) * BN, tile_id, seg, unit, kt_begin, kt_end, is_split);
+}
+
 // ---------------------------------------------------------------- split-K workspaces (caller-owned)
 // One workspace = fp32 partial-tile slabs + arrival counters.  A workspace must never be shared by two launches that can run
 // at the same time, so they are registered per (device, stream): a launch on stream s of device d uses the workspace attached
@@ -520,6 +552,10 @@ extern "C" int rtv_gemm_debug_timeline(unsigned long long* buf) {
 #endif
 
 extern "C" int rtv_gemm_set_skip_idle(int on) {
+  if (on == 2 || on == 3) {   // (second lab switch on the same entry: the half-tile tail of gemm8)
+    rtv::g_gemm8_half_tail = on == 3;
+    return 0;
+  }
   rtv::g_gemm8_skip_idle = on != 0;
   return 0;
 }
@@ -536,7 +572,7 @@ extern "C" int rtv_gemm_set_stream_workspace(rtv_stream_t stream, void* ptr, siz
 
 namespace rtv {
 
-int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream) {
+int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream, bool allow_half) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return set_error(-1, "gemm: cannot query the device");
   float* slabs = nullptr;
@@ -564,9 +600,20 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       }
     }
   }
-  *sp = SplitArgs{T, 1, nullptr, nullptr, 0, 0};
+  *sp = SplitArgs{T, 1, nullptr, nullptr, 0, 0, 0};
   *grid = T;
   const int R = T % G;
+  // A tail that split-K would cut in TWO (R between G / 3 and G / 2 tiles): run it as 2 R half tiles (128 x 256, full K) instead -
+  // the same parallelism without two prologues, a 256 KiB publish and a slab read per tile (tail cost 0.7-0.9 -> ~0.6 of a tile
+  // time at K = 5120: o-projection 201 -> 193 us, QKV unchanged; at K = 13824 the K segments are long enough to win by 2 %:
+  // profiles/r03_gemm_half_tail_ab.log); needs no workspace and keeps the unsplit summation order (bit-identical with config 4)
+  if (allow_half && g_gemm8_half_tail && R > 0 && T > R && G / R == 2 && nk <= 128) {
+    sp->first_unit = T - R;
+    sp->tail_tiles = R;
+    sp->half_tail = 1;
+    *grid = (T - R) + 2 * R;
+    return 0;
+  }
   if (allow_split && slabs && R > 0) {   // T < G (small M under context parallelism): every tile is a split tile
     int S = G / R;                 // the split units of the partial round still fit one round
     if (S > 8) S = 8;
@@ -600,7 +647,7 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   }
   SplitArgs sp;
   int grid = 0;
-  if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8::BK, allow_split, &sp, &grid, stream)) return st;
+  if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8::BK, allow_split, &sp, &grid, stream, /*allow_half=*/true)) return st;
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8::LDS_BYTES, stream, p, sp);
   return check_launch("gemm8");

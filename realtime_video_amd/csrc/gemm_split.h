@@ -22,11 +22,13 @@ struct SplitArgs {
                     // tile puts its counter back to zero)
   int tail_tiles;   // R: number of split tiles (block ids first_unit .. first_unit + R * S)
   int split_first;  // 1: the split units get the lowest block ids (dispatched first): chosen when there are few of them
+  int half_tail;    // 1 (gemm8 only): the R tail tiles run as 2 R units of 128 x 256 (rows 0-127 / 128-255 of the tile, full K, the
+                    // 128-row ping-pong body) instead of K segments: no slabs, no reduction; S is 1 then
 };
 
 // host: decide the split for T tiles of nk K-tiles each (defined in gemm8.hip, which owns the workspace pointers).
 // Fills *sp / *grid.  Returns 0 or an error status.
-int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream);
+int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream, bool allow_half = false);
 
 // device: block id -> (tile, K segment).  Returns true when this workgroup is a split unit.
 // The units of the tail round are laid out for L2 locality like the full tiles are: every XCD gets a contiguous chunk of the

@@ -33,13 +33,16 @@ for m in [int(x) for x in os.environ.get("CP_M", "4680,2340,1170,585").split(","
         w = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
         b = torch.randn(n, device="cuda").to(torch.bfloat16)
         out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
-        # cfg >= 1000: the same tile config with the idle-wave skipping of gemm8 switched off (A/B)
+        # cfg >= 1000: the same tile config with the idle-wave skipping of gemm8 switched off (A/B); cfg 3000 + c: tile config c with
+        # the half-tile tail of gemm8 switched off (K-segment tail instead)
         lib = __import__("realtime_video_amd._lib", fromlist=["load"]).load()
 
         def variant(c):
             def run():
-                lib.rtv_gemm_set_skip_idle(0 if c >= 1000 else 1)
+                lib.rtv_gemm_set_skip_idle(0 if 1000 <= c < 2000 else 1)
+                lib.rtv_gemm_set_skip_idle(2 if c >= 3000 else 3)
                 ops.gemm(a, w, bias=b, out=out, tile_cfg=c % 1000)
+                lib.rtv_gemm_set_skip_idle(3)
             return run
         fns = {f"cfg{c}": variant(c) for c in cfgs}
         if os.environ.get("CP_TORCH", "1") == "1":
