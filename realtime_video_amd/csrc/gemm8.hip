@@ -335,7 +335,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 // waits with vmcnt(6) - everything but the pieces it has just issued - so each piece is in flight for two to three
 // intervals before the counted wait retires it, one barrier before its first reader.
 static bool g_gemm8_skip_idle = true;   // rtv_gemm_set_skip_idle(0): A/B (lab)
-static bool g_gemm8_half_tail = true;   // rtv_gemm_set_skip_idle(2 / 3): half-tile tail off / on (A/B)
+static bool g_gemm8_half_tail = true;   // rtv_gemm_set_half_tail(0): K-segment tail instead (A/B)
 namespace g8m {
 constexpr int BM = 128, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
@@ -551,11 +551,12 @@ extern "C" int rtv_gemm_debug_timeline(unsigned long long* buf) {
 }
 #endif
 
+extern "C" int rtv_gemm_set_half_tail(int on) {   // A/B switch (lab, tests): the half-tile tail round of gemm8
+  rtv::g_gemm8_half_tail = on != 0;
+  return 0;
+}
+
 extern "C" int rtv_gemm_set_skip_idle(int on) {
-  if (on == 2 || on == 3) {   // (second lab switch on the same entry: the half-tile tail of gemm8)
-    rtv::g_gemm8_half_tail = on == 3;
-    return 0;
-  }
   rtv::g_gemm8_skip_idle = on != 0;
   return 0;
 }

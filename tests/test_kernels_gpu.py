@@ -564,6 +564,27 @@ def test_gemm_split_k_sum_order_is_fixed(ops):
         assert rel_l2(first, ref) <= 1e-2
 
 
+def test_gemm_half_tile_tail_is_bit_identical_with_the_plain_launch(ops):
+    """gemm8's tail round as 128 x 256 half tiles (a tail that split-K would cut in two, K <= 8192: 380 and 1140 tiles on 256 CUs)
+    through the 128-row body inside the same kernel: full K per unit, the unsplit summation order - the same bits as the launch
+    without it (rtv_gemm_set_half_tail(0), tile config 4 = no split-K either), for both epilogue families and a ragged M."""
+    from realtime_video_amd import _lib
+    lib = _lib.load()
+    try:
+        for M, N, K in ((4680, 5120, 1024), (4680, 15360, 512), (4500, 5120, 2048)):
+            a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+            r = _randn(M, N, seed=4)
+            outs = []
+            for on in (1, 0):
+                lib.rtv_gemm_set_half_tail(on)
+                outs.append((ops.gemm(a, w, bias=b, act=1, tile_cfg=4).clone(), ops.gemm(a, w, bias=b, residual=r, tile_cfg=4).clone()))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (M, N, K)
+            lib.rtv_gemm_set_half_tail(1)
+            assert rel_l2(ops.gemm(a, w, bias=b, tile_cfg=0), a.float() @ w.float().t() + b.float()) <= 1e-2
+    finally:
+        lib.rtv_gemm_set_half_tail(1)
+
+
 def test_idle_wave_loops_change_nothing_but_the_time(ops):
     """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
     only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
