@@ -219,13 +219,9 @@ def main():
         model.enable_fp8()
     use_cp = world > 1 and args.parallel == "cp"
     cp_world = world if use_cp else max(1, args.simulate_cp)
-    if args.cp_attn_splits <= 0:
-        # workgroups of one rank's launch: heads x 256-row query tiles / ranks (either exchange), one per CU at a time: rounds of
-        # 256; S key ranges make S x as many workgroups of 1/S the length (+ ~6 % per extra range for the merge and the per-
-        # workgroup prologue: profiles/r03_attn_kv_split_ab.log).  2 ranks: 380 -> 2 rounds, S = 2 -> 3 half rounds; 8 ranks: 95 -> S = 2
-        g_wg = max(1, mc["num_heads"] * 19 // cp_world)
-        cost = {sp: -(-g_wg * sp // 256) / sp * (1 + 0.06 * (sp - 1)) for sp in (1, 2, 4) if sp <= cp_world}
-        args.cp_attn_splits = min(cost, key=lambda sp: (cost[sp], sp)) if cp_world > 1 else 1
+    if args.cp_attn_splits <= 0:   # the count that fills the 256 CUs best for this rank count (parallel.attn_kv_splits_for)
+        from realtime_video_amd.parallel import attn_kv_splits_for
+        args.cp_attn_splits = attn_kv_splits_for(cp_world, mc["num_heads"])
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
         model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap,

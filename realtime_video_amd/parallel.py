@@ -46,6 +46,18 @@ class _ExchangeChoice:
         return True
 
 
+def attn_kv_splits_for(world, num_heads, q_tiles=19, cus=256):
+    """How many key ranges a context-parallel rank's self-attention launch should be cut into (ContextParallel(attn_kv_splits=)).
+    One rank's launch has num_heads x q_tiles / world workgroups (either exchange), one per CU at a time: rounds of `cus`.  S
+    ranges make S x as many workgroups of 1/S the length, + ~6 % per extra range for the merge kernel and the per-workgroup
+    prologue (profiles/r03_attn_kv_split_ab.log).  14B (40 heads): 2 / 4 / 2 ranges at 2 / 4 / 8 ranks; 1 rank: 1."""
+    if world <= 1:
+        return 1
+    g = max(1, num_heads * q_tiles // world)
+    cost = {s: -(-g * s // cus) / s * (1 + 0.06 * (s - 1)) for s in (1, 2, 4) if s <= world}
+    return min(cost, key=lambda s: (cost[s], s))
+
+
 class Pending:
     """A collective in flight (issued with async_op=True on the process group's communication stream, RCCL running beside the
     compute stream) plus the work that has to follow it; `wait()` makes the CURRENT stream wait for it - the host does not

@@ -192,3 +192,15 @@ def test_gather_row_stripes_world2():
         for H in (16, 15):
             full = torch.arange(2 * 3 * H * 4, dtype=torch.float32).view(2, 3, H, 4)
             assert torch.equal(ret[rank][H], full), (rank, H)
+
+
+def test_attn_kv_split_rule():
+    """parallel.attn_kv_splits_for: the number of key ranges that fills 256 CUs best for a rank's attention launch (bench.py uses it
+    for --cp-attn-splits 0): 14B -> 1 / 2 / 4 / 2 at 1 / 2 / 4 / 8 ranks, never more ranges than ranks (the partials share the
+    DiT workspace: splits x local heads <= heads)."""
+    from realtime_video_amd.parallel import attn_kv_splits_for
+    assert [attn_kv_splits_for(w, 40) for w in (1, 2, 4, 8)] == [1, 2, 4, 2]
+    for heads in (12, 16, 40):
+        for w in (1, 2, 4, 8):
+            s = attn_kv_splits_for(w, heads)
+            assert s in (1, 2, 4) and s <= max(1, w)
