@@ -24,9 +24,13 @@
 // later (after a barrier every wave has passed).  The LDS image is lane-linear per DMA piece; the bank swizzle is applied
 // to the per-lane source chunk and again on the ds_read_b128 (same involution).
 //
-// Tail-wave quantisation (e.g. 380 tiles on 256 CUs = 1.48 rounds) is removed by splitting the K range of the tiles of the
-// last, partial round over S workgroups; partial accumulators go through an fp32 slab in a caller-provided workspace and
-// the last arriver (agent-scope release / acquire + arrival counter) sums them and runs the epilogue.
+// Tail-wave quantisation (e.g. 380 tiles on 256 CUs = 1.48 rounds), three forms chosen by plan_split_k (r03):
+//   * a tail that would be cut in two, K <= 8192: its tiles run as 128 x 256 HALF TILES with full K through the 128-row body
+//     (gemm8m_body) inside this kernel - no slabs, no reduction, the unsplit summation order;
+//   * else the K range of the tail tiles is split over S workgroups; partial accumulators go through an fp32 slab in a
+//     caller-provided workspace and the last arriver (agent-scope release / acquire + arrival counter) sums them - for S > 2 all
+//     S slabs in index order, so the arrival order never shows in the result - and runs the epilogue;
+//   * a handful of split units (R x S <= CUs / 4) is dispatched FIRST, beside the first full tiles, instead of as a last round.
 #include <mutex>
 #include <type_traits>
 
