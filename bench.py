@@ -329,6 +329,13 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(out.float()).all(), "non-finite output"
+    # fingerprint of the LAST block's denoised latents ([1, 3, 16, 60, 104] bf16; seeds fixed): two builds / two boxes can be
+    # compared - sha256 of the bytes (equal only if the kernels sum in the same order) and two order-insensitive moments
+    import hashlib
+    lat = sess.last_pred.detach().float().cpu()
+    latents_checksum = {"sha256_bf16": hashlib.sha256(sess.last_pred.detach().cpu().contiguous().view(torch.int16).numpy().tobytes()).hexdigest()[:16],
+                        "abs_sum": float(lat.double().abs().sum()), "mean": float(lat.double().mean()),
+                        "shape": list(lat.shape)}
 
     step_ms = [e0.elapsed_time(e1) for rc, e0, e1 in wr.events if not rc]
     recompute_ms = [e0.elapsed_time(e1) for rc, e0, e1 in wr.events if rc]
@@ -384,6 +391,7 @@ def main():
             # host side of a block: the session loop's wall time, the part of it spent blocked on the previous block's frames
             # (a wait on the GPU, not work) and the rest = Python + ctypes launch issue (6 ms under --hipgraph)
             "host_ms_per_block": host_ms,
+            "last_block_latents_checksum": latents_checksum,
         },
         "roofline": {
             "kernel": "gemm8_kernel / gemm_kernel (bf16 MFMA projection GEMMs with fused epilogues: all DiT linears)",

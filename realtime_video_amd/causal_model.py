@@ -108,10 +108,9 @@ class _SelfAttnHandle:
         self.fused_projections = True  # q/k/v are always stored fused here
         # fixed at construction like the reference (causal_model.py:192): later writes to local_attn_size
         # (release_server.py:544-546 sets -1) do not change the attention window
+        # The window is this many TOKENS at every resolution, exactly as in the reference (:192, :388-389): with a 32760-row
+        # cache at a lower resolution (fs = 390: 84 frames fit) the whole cache is attended, at a higher one fewer frames.
         self.max_attention_size = 32760 if local_attn_size == -1 else local_attn_size * 1560
-        # the same window in FRAMES (32760 = 21 frames of 1560 tokens): at another resolution the session's caches are sized in
-        # that resolution's tokens per frame, and a window of max_attention_size tokens would cut mid-frame
-        self.window_frames = 21 if local_attn_size == -1 else local_attn_size
 
     def fuse_projections(self):
         self.fused_projections = True
@@ -400,7 +399,7 @@ class CausalWanModel:
         local_start = local_end - num_new
         if local_start < 0 or local_end > kv_size:
             raise RuntimeError(f"KV cache window [{local_start}, {local_end}) outside cache of {kv_size} rows")
-        lo = max(0, local_end - (sa.max_attention_size if frame_seqlen == 1560 else sa.window_frames * frame_seqlen))
+        lo = max(0, local_end - sa.max_attention_size)      # causal_model.py:388-389: a window in tokens, whatever the frame size
         if ring_start == 0:
             ring_lo = ring_size = 0         # unrotated: logical == physical
 
@@ -417,7 +416,7 @@ class CausalWanModel:
         return local_start, lo, local_end, current_start // frame_seqlen, 0, (ring_lo, ring_size, ring_start), commit
 
     def _forward_inference(self, x, t, context, seq_len=None, clip_fea=None, y=None, kv_cache=None,
-                           crossattn_cache=None, current_start=0, cache_start=0):
+                           crossattn_cache=None, current_start=0, cache_start=0, kv_cache_only=False):
         if self._w is None:
             raise RuntimeError("weights not loaded")
         if kv_cache is None or crossattn_cache is None:
@@ -456,10 +455,11 @@ class CausalWanModel:
                 c["text_rows"] = n_real
         cp = self.context_parallel
         use_cp = cp is not None and cp.world > 1
-        # `kv_cache_only` (set by the session around its KV-recompute pass, whose output the reference discards as well,
-        # release_server.py:611-632): the forward stops behind the last layer's K / V cache write; the returned tensor is zeros
-        # (not while the cross-attention caches are still to be filled: the last layer's text K / V are computed in its rest phase)
-        kv_only = bool(getattr(self, "kv_cache_only", False)) and not need_cross
+        # `kv_cache_only` (a per-CALL argument, not in the reference signature: the session passes it for its KV-recompute pass,
+        # whose output the reference discards as well, release_server.py:611-632): the forward stops behind the last layer's
+        # K / V cache write; the returned tensor is zeros (not while the cross-attention caches are still to be filled: the last
+        # layer's text K / V are computed in its rest phase).  Model state is not touched: sessions sharing the model cannot see it.
+        kv_only = bool(kv_cache_only) and not need_cross
         text_rows = int(crossattn_cache[0].get("text_rows", 0)) if getattr(self, "fold_text_padding", True) else 0
         if text_rows <= 0 or any(int(c.get("text_rows", 0)) != text_rows for c in crossattn_cache):
             text_rows = 0        # unknown (caches filled elsewhere) or inconsistent: attend all text_len rows

@@ -229,13 +229,11 @@ class GenerationSession:
         t0 = torch.zeros([ctx.shape[0], ctx.shape[1]], device=ctx.device, dtype=torch.int64)
         # the pass only fills the KV cache, its output is discarded here as in the reference: the native model may stop behind
         # the last layer's cache write (everything after it - 2 % of the forward - is dead work)
-        model.kv_cache_only = True
         try:
             models.transformer(noisy_image_or_video=ctx, conditional_dict=self.conditional_dict, timestep=t0,
                                kv_cache=pipe.kv_cache1, crossattn_cache=pipe.crossattn_cache,
-                               current_start=start * pipe.frame_seq_length)
+                               current_start=start * pipe.frame_seq_length, kv_cache_only=True)
         finally:
-            model.kv_cache_only = False
             model.block_mask = None
         return start
 

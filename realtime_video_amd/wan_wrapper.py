@@ -41,16 +41,18 @@ class WanDiffusionWrapper:
         return (x - sig[idx].reshape(-1, 1, 1, 1) * fp).to(dt)
 
     def forward(self, noisy_image_or_video, conditional_dict, timestep, kv_cache=None, crossattn_cache=None,
-                current_start=None, cache_start=None, renoise=None, **unused):
+                current_start=None, cache_start=None, renoise=None, kv_cache_only=False, **unused):
         """`renoise=(noise[B*F,16,h,w], next_timestep[B*F])` (not in the reference signature): also return
         scheduler.add_noise(x0, noise, next_timestep) as a third value, computed in the same launch as x0 - the
-        denoising loops of release_server.py:669-694 / causal_inference.py:187-212 call the two back to back."""
+        denoising loops of release_server.py:669-694 / causal_inference.py:187-212 call the two back to back.
+        `kv_cache_only=True` (not in the reference signature either): the caller discards the output and only wants the K / V
+        cache filled (the session's recompute pass); the model may stop behind the last layer's cache write."""
         if kv_cache is None:
             raise NotImplementedError("non-cached (training / bidirectional) forwards are out of scope")
         flow = self.model(noisy_image_or_video.permute(0, 2, 1, 3, 4), t=timestep,
                           context=conditional_dict["prompt_embeds"], seq_len=self.seq_len, kv_cache=kv_cache,
                           crossattn_cache=crossattn_cache, current_start=current_start,
-                          cache_start=cache_start).permute(0, 2, 1, 3, 4)
+                          cache_start=cache_start, kv_cache_only=kv_cache_only).permute(0, 2, 1, 3, 4)
         fl, xt, ts = flow.flatten(0, 1), noisy_image_or_video.flatten(0, 1), timestep.flatten(0, 1)
         if renoise is None:
             return flow, self._convert_flow_pred_to_x0(fl, xt, ts).unflatten(0, flow.shape[:2])

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # Collection order on the GPU box: kernel-level parity first, then the VAE, the text encoder, the model / session level and
 # the two-process runs last - a slow box must never hide the kernel evidence behind end-to-end tests (GPUTEST_r02).
 _FILE_ORDER = ["test_kernels_gpu.py", "test_vae_gpu.py", "test_text_encoder_gpu.py", "test_dit_gpu.py",
-               "test_context_parallel_gpu.py"]
+               "test_depth_gpu.py", "test_context_parallel_gpu.py"]
 PER_TEST_TIMEOUT_S = 180
 
 

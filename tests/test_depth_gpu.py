@@ -1,0 +1,172 @@
+"""Full-DEPTH parity on the MI355X at BASELINE width: the whole layer stack of the 14B architecture (40 layers, d 5120,
+wan/configs/wan_t2v_14B.py:21-25) and of the 1.3B architecture (30 layers, d 1536, wan_t2v_1_3B.py:21-25) driven through
+whole blocks of the session loop (KV-recompute forward + 4 denoise forwards, release_server.py:588-736) against the oracle
+graph (oracle/wan_oracle.SessionOracle; its host evaluation is pinned to the reference's goldens by the CPU suite) evaluated
+by torch eager on the device over THE SAME weight tensors, in bf16 (the reference's arithmetic) and in fp32 (gold).
+
+Stated tolerance: end-of-block latents rel-L2(ours, bf16 oracle) <= 2e-2, the cache indices exact,
+err(ours, fp32 gold) <= 2 x err(bf16 oracle, fp32 gold) (+ a small floor), K / V cache rows of the first, a middle and the last
+layer rel-L2 <= 2e-2.  `scripts/depth_error_curve.py` writes the error-vs-depth curve of the same setup to profiles/."""
+import pytest
+import torch
+
+from conftest import max_abs, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+ARCH = {
+    "14b": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40),
+    "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30),
+}
+
+
+def native_model(arch, text_dim=4096, seed=0, num_layers=None, share=None):
+    """The native model with synthetic weights generated on the device (`init_random_weights`), or - `share` - a model of
+    fewer layers over the SAME tensors as `share` (load_state_dict keeps device bf16 tensors as they are)."""
+    from realtime_video_amd.causal_model import CausalWanModel
+    from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
+    a = dict(ARCH[arch])
+    if num_layers is not None:
+        a["num_layers"] = num_layers
+    m = CausalWanModel(dim=a["dim"], ffn_dim=a["ffn_dim"], num_heads=a["num_heads"], num_layers=a["num_layers"],
+                       text_dim=text_dim, freq_dim=256, device=DEV)
+    if share is None:
+        m.init_random_weights(seed=seed)
+    else:
+        m.load_state_dict(reference_state_dict(share))
+    cfg = dict(a, freq_dim=256, text_len=512, eps=1e-6, num_frame_per_block=3)
+    return m, WanDiffusionWrapper(m, timestep_shift=5.0), cfg
+
+
+def reference_state_dict(model):
+    """The native model's weights under the reference's state_dict names (wan/modules/causal_model.py module tree), as VIEWS of
+    the tensors the kernels read (q / k / v = row blocks of the fused to_qkv): the oracle graph and the native forward share one
+    copy of the 28.6 GB."""
+    t, d = model._tensors, model.dim
+    sd = {"patch_embedding.weight": t["patch_w"].view(d, model.in_dim, 1, 2, 2), "patch_embedding.bias": t["patch_b"],
+          "head.modulation": t["head_modulation"].view(1, 2, d)}
+    for dst, src in (("text0", "text_embedding.0"), ("text2", "text_embedding.2"), ("time0", "time_embedding.0"),
+                     ("time2", "time_embedding.2"), ("tproj", "time_projection.1"), ("head", "head.head")):
+        sd[src + ".weight"], sd[src + ".bias"] = t[dst + "_w"], t[dst + "_b"]
+    for i in range(model.num_layers):
+        p, g = f"blocks.{i}", lambda n, i=i: t[f"L{i}.{n}"]
+        for j, m in enumerate(("q", "k", "v")):
+            sd[f"{p}.self_attn.{m}.weight"] = g("qkv_w")[j * d:(j + 1) * d]
+            sd[f"{p}.self_attn.{m}.bias"] = g("qkv_b")[j * d:(j + 1) * d]
+        sd[f"{p}.self_attn.o.weight"], sd[f"{p}.self_attn.o.bias"] = g("o_w"), g("o_b")
+        sd[f"{p}.self_attn.norm_q.weight"], sd[f"{p}.self_attn.norm_k.weight"] = g("norm_q_w"), g("norm_k_w")
+        for m in ("q", "k", "v", "o"):
+            sd[f"{p}.cross_attn.{m}.weight"], sd[f"{p}.cross_attn.{m}.bias"] = g(f"c{m}_w"), g(f"c{m}_b")
+        sd[f"{p}.cross_attn.norm_q.weight"], sd[f"{p}.cross_attn.norm_k.weight"] = g("cnorm_q_w"), g("cnorm_k_w")
+        sd[f"{p}.norm3.weight"], sd[f"{p}.norm3.bias"] = g("norm3_w"), g("norm3_b")
+        sd[f"{p}.ffn.0.weight"], sd[f"{p}.ffn.0.bias"] = g("ffn0_w"), g("ffn0_b")
+        sd[f"{p}.ffn.2.weight"], sd[f"{p}.ffn.2.bias"] = g("ffn2_w"), g("ffn2_b")
+        sd[f"{p}.modulation"] = t["modulation"][i].view(1, 6, d)
+    return sd
+
+
+def fp32_attention(q, k, v):
+    """The gold graph's attention: softmax(q k^T / sqrt(d)) v in fp32, one head group at a time (the full fp32 score tensor of
+    40 heads x 14040^2 does not have to exist at once)."""
+    from oracle import wan_oracle as wo
+    H = q.shape[2]
+    step = max(1, min(H, int(2e9 // max(1, q.shape[1] * k.shape[1]))))
+    return torch.cat([wo.attention_math(q[:, :, h:h + step], k[:, :, h:h + step], v[:, :, h:h + step])
+                      for h in range(0, H, step)], dim=2)
+
+
+def native_session(model, wr, text_dim, ctx, noise, blocks, seed, c=3):
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250]),
+                                   DEV, generator=wr, text_encoder=None, vae=None)
+    padded = torch.zeros(1, 512, text_dim, dtype=torch.bfloat16, device=DEV)
+    padded[0, :ctx.shape[0]] = ctx
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(padded))
+    sess = GenerationSession(GenerateParams(seed=seed, num_blocks=blocks, num_denoising_steps=4, keep_first_frame=True,
+                                            kv_cache_num_frames=c), models, device=DEV)
+    sess.noise = noise
+    cpu_rnd = torch.Generator().manual_seed(seed)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    return sess, pipe
+
+
+def run_depth_case(arch, blocks=2, text_dim=4096, gold=True, seed=9):
+    """-> dict of per-block errors; used by the tests below and by scripts/depth_error_curve.py."""
+    from oracle import wan_oracle as wo
+    model, wr, cfg = native_model(arch, text_dim=text_dim, seed=0)
+    sd = reference_state_dict(model)
+    g = torch.Generator().manual_seed(5)
+    ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16).to(DEV)
+    noise = torch.randn(1, 3 * blocks, 16, 60, 104, generator=g).to(torch.bfloat16).to(DEV)
+    with torch.inference_mode():
+        ora = wo.SessionOracle(sd, cfg, [ctx], noise, kv_cache_num_frames=3, num_steps=4, shift=5.0, seed=seed)
+        ref = [ora.generate_block().clone() for _ in range(blocks)]
+        ref_kv = {l: (ora.kv_cache[l]["k"][0, ::197].clone(), ora.kv_cache[l]["v"][0, ::197].clone())
+                  for l in (0, cfg["num_layers"] // 2, cfg["num_layers"] - 1)}
+        ref_idx = [(c["global_end_index"], c["local_end_index"]) for c in ora.kv_cache]
+        del ora
+        gold_blocks = None
+        if gold:
+            sd32 = {k: v.float() for k, v in sd.items()}
+            og = wo.SessionOracle(sd32, cfg, [ctx.float()], noise.float(), kv_cache_num_frames=3, num_steps=4, shift=5.0,
+                                  seed=seed, attn_fn=fp32_attention)
+            gold_blocks = [og.generate_block().clone() for _ in range(blocks)]
+            del og, sd32
+            torch.cuda.empty_cache()
+    sess, pipe = native_session(model, wr, text_dim, ctx, noise, blocks, seed)
+    ours = [sess.generate_block().clone() for _ in range(blocks)]
+    res = {"cfg": cfg, "blocks": []}
+    for b in range(blocks):
+        e = {"rel_l2_vs_oracle": rel_l2(ours[b], ref[b]), "max_abs_vs_oracle": max_abs(ours[b], ref[b])}
+        if gold_blocks is not None:
+            e.update(rel_l2_vs_gold=rel_l2(ours[b], gold_blocks[b]), oracle_rel_l2_vs_gold=rel_l2(ref[b], gold_blocks[b]),
+                     max_abs_vs_gold=max_abs(ours[b], gold_blocks[b]), oracle_max_abs_vs_gold=max_abs(ref[b], gold_blocks[b]))
+        res["blocks"].append(e)
+    res["indices"] = [(int(c["global_end_index"]), int(c["local_end_index"])) for c in pipe.kv_cache1]
+    res["ref_indices"] = ref_idx
+    res["kv"] = {l: (rel_l2(pipe.kv_cache1[l]["k"][0, ::197], rk), rel_l2(pipe.kv_cache1[l]["v"][0, ::197], rv))
+                 for l, (rk, rv) in ref_kv.items()}
+    res["finite"] = all(bool(torch.isfinite(o.float()).all()) for o in ours)
+    return res
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("arch", ["1.3b", "14b"])
+def test_full_depth_two_blocks_match_oracle_and_fp32_gold(arch):
+    """Block 0 (4 denoise forwards over a growing 4680-row window) and block 1 (KV-recompute over the 3 context frames with the
+    block-causal mask + 4 denoise forwards over 9360 rows) of the session loop on the FULL layer stack at production width."""
+    r = run_depth_case(arch, blocks=2, gold=True)
+    assert r["finite"]
+    assert r["indices"] == r["ref_indices"] and r["indices"][0] == (9360, 9360)      # bookkeeping exact, every layer
+    for b, e in enumerate(r["blocks"]):
+        assert e["rel_l2_vs_oracle"] <= 2e-2, (arch, b, e)
+        assert e["rel_l2_vs_gold"] <= 2 * e["oracle_rel_l2_vs_gold"] + 2e-3, (arch, b, e)
+        assert e["max_abs_vs_gold"] <= 2 * e["oracle_max_abs_vs_gold"] + 1e-2, (arch, b, e)
+    for l, (ek, ev) in r["kv"].items():
+        assert ek <= 2e-2 and ev <= 2e-2, (arch, l, ek, ev)
+
+
+@pytest.mark.timeout(600)
+def test_full_width_layer_long_context_c9_matches_oracle():
+    """BASELINE config 5's context length at production WIDTH: kv_cache_num_frames = 9 (18720-row window; the recompute pass
+    of block 3 covers nine context frames = 14040 tokens under the block-causal mask of three 3-frame blocks) on one layer of
+    the 14B architecture, four blocks, against the bf16 oracle graph on the device."""
+    from oracle import wan_oracle as wo
+    model, wr, cfg = native_model("14b", text_dim=256, seed=3, num_layers=1)
+    sd = reference_state_dict(model)
+    g = torch.Generator().manual_seed(6)
+    ctx = torch.randn(40, 256, generator=g).to(torch.bfloat16).to(DEV)
+    noise = torch.randn(1, 12, 16, 60, 104, generator=g).to(torch.bfloat16).to(DEV)
+    with torch.inference_mode():
+        ora = wo.SessionOracle(sd, cfg, [ctx], noise, kv_cache_num_frames=9, num_steps=4, shift=5.0, seed=4)
+        ref = [ora.generate_block().clone() for _ in range(4)]
+    sess, pipe = native_session(model, wr, 256, ctx, noise, 4, seed=4, c=9)
+    for b in range(4):
+        out = sess.generate_block()
+        assert rel_l2(out, ref[b]) <= 2e-2, b
+    assert pipe.kv_cache1[0]["k"].shape[1] == 12 * 1560
+    assert (int(pipe.kv_cache1[0]["global_end_index"]), int(pipe.kv_cache1[0]["local_end_index"])) == \
+        (ora.kv_cache[0]["global_end_index"], ora.kv_cache[0]["local_end_index"]) == (18720, 18720)
+    assert rel_l2(pipe.kv_cache1[0]["k"][0, :18720:97], ora.kv_cache[0]["k"][0, :18720:97]) <= 2e-2

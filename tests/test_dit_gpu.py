@@ -322,6 +322,32 @@ def test_session_at_another_resolution_uses_its_own_frame_length(monkeypatch):
     assert pipe.kv_cache1[0]["local_end_index"] == 6 * 390
 
 
+def test_attention_window_is_counted_in_tokens_at_every_resolution(monkeypatch):
+    """the self-attention window is max_attention_size TOKENS (32760, or local_attn_size * 1560) at every
+    resolution, as in the reference (causal_model.py:192, :388-389) - not a number of frames.  416 x 240 (390 tokens per frame)
+    with the pipeline's 32760-row cache: after 8 blocks 9360 rows are live, more than 21 frames' worth (8190) - a frame-counted
+    window would drop the oldest three frames, the reference (and the oracle with the same frame length) attends them all."""
+    from oracle import wan_oracle as wo
+    monkeypatch.setattr(wo, "FRAME_SEQLEN", 390)
+    cfg, text_dim, _ = _tiny()
+    cfg["num_layers"] = 1
+    w = wo.make_weights(cfg, seed=2, text_dim=text_dim)
+    g = torch.Generator().manual_seed(8)
+    ctx = torch.randn(32, text_dim, generator=g).to(torch.bfloat16)
+    lat = torch.randn(8, 1, 3, 16, 30, 52, generator=g).to(torch.bfloat16)
+    kvc = wo.initialize_kv_cache(1, 1, 32760, cfg["num_heads"], 128, torch.bfloat16, DEV)
+    cac = wo.initialize_crossattn_cache(1, 1, cfg["num_heads"], 128, torch.bfloat16, device=DEV)
+    model, wr = _build(cfg, text_dim, w)
+    kv, ca = _caches(cfg, 32760)
+    t = torch.ones([1, 3], dtype=torch.int64, device=DEV) * 500
+    wd = _on_dev(w)
+    for b in range(8):
+        ref, _ = wo.wrapper_forward(wd, cfg, wo.FlowMatchScheduler(), lat[b].to(DEV), [ctx.to(DEV)], t, kvc, cac, b * 1170)
+        flow, _ = wr(lat[b].to(DEV), {"prompt_embeds": [ctx.to(DEV)]}, t, kv, ca, current_start=b * 1170)
+        assert rel_l2(flow, ref) <= 2e-2, b
+    assert kv[0]["local_end_index"] == kvc[0]["local_end_index"] == 9360
+
+
 @pytest.mark.parametrize("world,exchange,heads", [(2, "rows", 2), (8, "rows", 2), (2, "heads", 2), (4, "heads", 8),
                                                   (8, "heads", 8)])
 def test_context_parallel_phase_api_equals_unsharded(world, exchange, heads):
@@ -724,7 +750,7 @@ def test_cross_attention_padding_fold_matches_full_text_window(golden):
 
 @pytest.mark.parametrize("cp_world", [0, 2])
 def test_kv_cache_only_forward_fills_the_same_cache(cp_world):
-    """`model.kv_cache_only` (what the session sets around its KV-recompute pass, whose output the reference discards,
+    """`kv_cache_only=True` (a per-call argument; what the session passes for its KV-recompute pass, whose output the reference discards,
     release_server.py:611-632): the forward stops behind the last layer's cache write - the KV caches of EVERY layer are bit-identical
     to those of the full recompute forward, the indices advance the same way, the returned tensor is zeros; with the
     cross-attention caches still uninitialised the switch is ignored (the last layer's text K / V are computed in its rest
@@ -743,13 +769,11 @@ def test_kv_cache_only_forward_fills_the_same_cache(cp_world):
         kv, ca = _caches(cfg, 9360)
         cond = {"prompt_embeds": [ctx.to(DEV)]}
         model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560, num_frame_per_block=3)
-        model.kv_cache_only = only
-        first, _ = wr(lat[2].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680)    # cross caches uninitialised: full forward
+        first, _ = wr(lat[2].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680, kv_cache_only=only)   # cross caches uninitialised: full forward
         assert all(c["is_init"] for c in ca)
         for c in kv:
             c["global_end_index"] = c["local_end_index"] = 0
-        rc, _ = wr(lat[1].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680)        # the switch takes effect here
-        model.kv_cache_only = False
+        rc, _ = wr(lat[1].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680, kv_cache_only=only)      # the switch takes effect here
         model.block_mask = None
         nxt, _ = wr(lat[3].to(DEV), cond, t.to(DEV), kv, ca, current_start=4680)          # a denoise step on the recomputed cache
         res[only] = (first, rc, nxt, [c["k"].clone() for c in kv], [c["v"].clone() for c in kv],
