@@ -21,6 +21,8 @@ sys.path.insert(0, ROOT)
 MODELS = {
     "14b": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40, name="Krea-Realtime-14B (Wan2.1-T2V-14B arch)"),
     "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, name="Wan2.1-T2V-1.3B arch"),
+    # test rig only (tests/test_context_parallel_gpu.py drives the launcher path with it): 8 heads -> one head per rank at 8 ranks
+    "tiny": dict(dim=1024, ffn_dim=2048, num_heads=8, num_layers=2, name="TEST RIG (INVALID as a result): 2-layer d=1024 H=8"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md)
 MFMA_SUSTAINED_FP8_TFLOPS = 4350.0  # v_mfma_f32_32x32x64_f8f6f4 loop, random e4m3 operands (scripts/micro/fp8_mfma.hip)
@@ -221,7 +223,8 @@ def main():
     cp_world = world if use_cp else max(1, args.simulate_cp)
     if args.cp_attn_splits <= 0:   # the count that fills the 256 CUs best for this rank count (parallel.attn_kv_splits_for)
         from realtime_video_amd.parallel import attn_kv_splits_for
-        args.cp_attn_splits = attn_kv_splits_for(cp_world, mc["num_heads"])
+        args.cp_attn_splits = attn_kv_splits_for(cp_world, mc["num_heads"],
+                                                 cus=torch.cuda.get_device_properties(dev).multi_processor_count)
     if use_cp:
         from realtime_video_amd.parallel import ContextParallel
         model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap,
@@ -358,7 +361,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if use_cp else "weak",
         "vs_baseline": ((total_frames / elapsed) / 11.0
-                        if args.model == "14b" and world == 1 and not args.no_vae and not args.fp8 else None),
+                        if args.model == "14b" and world == 1 and not args.no_vae and not args.fp8 and not args.simulate_cp else None),
         "dtype": "fp8 e4m3 linears (per-tensor dynamic activations, fp32 accumulation), bf16 elsewhere" if args.fp8 else "bf16",
         "data": "synthetic (random-init weights of the named architecture, N(0,1) latents/noise, N(0,1) prompt embeddings)",
         "config": {

@@ -99,12 +99,6 @@ int rtv_attn_fwd_split(const void* q, const void* k, const void* v, void* o,
                        int64_t o_batch_stride, int64_t o_row_stride,
                        float scale, int causal_block, int q_offset,
                        int kv_splits, void* workspace, size_t workspace_bytes, int dtype, rtv_stream_t stream);
-/* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
- * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  256-row launches over >= 1024 keys run the
- * four-phase kernel (K/V by LDS DMA, fragments read a phase ahead of their MFMAs, the two wave groups one phase apart),
- * shorter windows the lockstep one; 81 / 82 force the lockstep / four-phase schedule.  All variants compute every row with
- * the same arithmetic in the same order (bit-identical outputs).  A tuning knob for A/B measurements and tests. */
-int rtv_attn_set_waves(int waves);
 
 /* ---- K4: projection GEMM with fused epilogue ---------------------------------------------
  * C[M,N] = epi(A[M,K] @ W[N,K]^T): replaces nn.Linear (causal_model.py:196-199,:246,:433-435,
@@ -216,6 +210,8 @@ typedef struct rtv_dit_config {
   int in_dim, out_dim;          /* latent channels (16, 16); patch size is (1,2,2) */
   float eps;
   int use_fp8;                  /* 1: every nn.Linear runs the e4m3 path (weights below are e4m3, fp8_scales set) */
+  int max_attn_kv_splits;       /* largest rtv_dit_step.attn_kv_splits this workspace must serve (0 / 1: none - the workspace then
+                                   holds no split-attention partials: 97 MB at 14B, M = 4680); a step asking for more fails */
 } rtv_dit_config;
 
 typedef struct rtv_dit_layer_weights { /* bf16 device pointers, reference state_dict names in comments */
@@ -272,7 +268,8 @@ typedef struct rtv_dit_step {
                                attention, o-projection, cross-attention, FFN, the head - is skipped, `out` is left untouched */
   int attn_kv_splits;       /* > 1: the self-attention launches of a token- or head-sharded call (rtv_dit_layer_attn_hp,
                                rtv_dit_layer_rest with row_count < M) cut their key window into this many ranges
-                               (rtv_attn_fwd_split); 0 / 1: one launch.  Not bit-identical with the unsplit forward. */
+                               (rtv_attn_fwd_split); 0 / 1: one launch.  Not bit-identical with the unsplit forward.  Must not
+                               exceed rtv_dit_config.max_attn_kv_splits (the workspace holds the partials): an error otherwise. */
 } rtv_dit_step;
 
 size_t rtv_dit_workspace_bytes(const rtv_dit_config* cfg, int F, int gh, int gw);
@@ -368,11 +365,10 @@ int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void*
 /* The first conv of a ResidualBlock with the RMS_norm * gamma + SiLU behind it (wan/modules/vae.py:186-192) in its epilogue:
  * out = SiLU(RMS_norm(conv3x3x3(in) + bias) * gamma), `in` = the causal concat buffer as for rtv_conv_cl.  Returns 1 - nothing
  * launched, no error - when the layer is not one the halo-tile conv kernel takes with all channels of a pixel in one workgroup
- * (Cout == 96, Cin % 32 == 0, not RTV_CONV_GATHER): run rtv_conv_cl + rtv_rmsnorm_silu_cl then.  rtv_conv_set_fuse_norm(0)
- * switches the fusion off (A/B; the two forms differ by the fp32 summation order of the 96 squares). */
+ * (Cout == 96, Cin % 32 == 0, not RTV_CONV_GATHER): run rtv_conv_cl + rtv_rmsnorm_silu_cl then.  (The two forms differ by
+ * the fp32 summation order of the 96 squares; include/rtv_hip_lab.h has the A/B switch.) */
 int rtv_conv3_norm_silu_cl(const void* in, const void* w, const void* bias, const void* gamma, void* out, int out_ld,
                            int T, int H, int W, int Cin, int Cout, int flags, const void* zeros, rtv_stream_t stream);
-int rtv_conv_set_fuse_norm(int on);
 /* RMS_norm over channels (+SiLU) on channels-last pixels (wan/modules/vae.py:39-54): C in {96,192,384}. */
 int rtv_rmsnorm_silu_cl(const void* x, void* out, const void* gamma, int C, int64_t npix, int apply_silu,
                         rtv_stream_t stream);
@@ -404,6 +400,13 @@ int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C, int* H, i
 /* z: fp16 [T][16][h][w] latents; pixels: float32 [T'][3][8h][8w] in [-1,1], T' = 4T (4T-3 when first). */
 int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first,
                    void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
+/* VAEDecoderWrapperSingle.forward (demo_utils/vae.py:150-195 over the VAEDecoder3d / Resample twins :50-123, :198-314): ONE latent
+ * frame per call, `is_first_frame` given by the caller, the feature caches always present (zeros before the first frame:
+ * demo_utils/constant.py:6-39).  z: fp16 [1][16][h][w]; pixels: float32 [4][3][8h][8w] in [-1,1] - also on the first frame, where
+ * this form interleaves a zero frame instead of skipping the temporal doubling (:112-116) and leaves the time_conv caches
+ * untouched (:86-90); after a later frame a time_conv cache is [zeros, x] (:106-111).  Same arena layout as rtv_vae_decode. */
+int rtv_vae_decode_single(const rtv_vae_weights* w, const void* z, int h, int wd, int is_first_frame,
+                          void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream);
 /* Output side of the decoder (the frame path of release_server.py:978-991 + :972): pixels float32 [T][3][H][W] in
  * [-1,1] -> rgb8 [T][H][W][3] = u8(trunc(clamp((x + 1) * 0.5, 0, 1) * 255)) - the bytes the reference hands to the JPEG encoder
  * (host-side add_(1).mul_(0.5).clamp_(0,1), then torchvision to_pil_image's mul(255).byte()) - computed on the GPU so that

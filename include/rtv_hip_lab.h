@@ -1,0 +1,43 @@
+/* Test and measurement hooks of librtv_hip.so - NOT part of the drop-in boundary (include/rtv_hip.h is; a reference-side
+ * binding never needs anything declared here).  These select between implementations of one entry point that compute the same
+ * result, so that tests can hold the variants against each other (bit-identity / stated tolerance) and scripts/ can time them.
+ * Each switch is one process-wide std::atomic read at launch time: flipping it while another thread launches is safe and
+ * affects only which variant later launches pick; none of them changes a result beyond what the declaration states.
+ *
+ * Experimental kernels (csrc/gemm4.hip, the timing-only tile configurations 81-91) are compiled only into the lab build
+ * (`make -C realtime_video_amd/csrc LAB=1` -> realtime_video_amd/librtv_hip_lab.so, -DRTV_LAB); the product library rejects those
+ * tile configurations. */
+#ifndef RTV_HIP_LAB_H
+#define RTV_HIP_LAB_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
+ * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  256-row launches over >= 1024 keys run the
+ * four-phase kernel (K/V by LDS DMA, fragments read a phase ahead of their MFMAs, the two wave groups one phase apart),
+ * shorter windows the lockstep one; 81 / 82 force the lockstep / four-phase schedule.  All variants compute every row with
+ * the same arithmetic in the same order (bit-identical outputs). */
+int rtv_attn_set_waves(int waves);
+
+/* gemm8 (256x256 ping-pong GEMM): tail round as 128x256 half tiles (default 1) or as K segments with an fp32 slab reduction (0).
+ * Half tiles keep the unsplit summation order (bit-identical with tile config 4). */
+int rtv_gemm_set_half_tail(int on);
+/* gemm8: waves whose 128 rows all lie beyond M run an idle loop (default 1) or the full K loop on clamped rows (0).  Bit-identical. */
+int rtv_gemm_set_skip_idle(int on);
+/* VAE decoder: RMS_norm + SiLU fused into the producing 96-channel conv (default 1) or as a separate pass (0); the two differ by
+ * the fp32 summation order of the 96 squares (tests: pixels within 2e-3). */
+int rtv_conv_set_fuse_norm(int on);
+/* Four-phase attention kernel: waves whose query rows all lie beyond Lq run an idle loop (default 1) or the full loop (0).
+ * Bit-identical. */
+int rtv_attn_set_skip_idle(int on);
+/* VAE 3x3x3 stride-1 convolutions on the halo-tile kernel (default 1) or on the implicit-GEMM gather kernel (0); same K order per
+ * output pixel (bit-identical). */
+int rtv_conv_set_halo(int on);
+/* 1 when the library was built with -DRTV_LAB (experimental kernels present), else 0. */
+int rtv_lab_build(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -183,6 +183,30 @@ def golden_vae(ref):
     print("vae_decoder.pt", [tuple(p.shape) for p in out["pixels"]])
 
 
+def golden_vae_single():
+    """VAEDecoderWrapperSingle (demo_utils/vae.py:150-195, the one-latent-frame form): first frame on the zero caches of
+    demo_utils/constant.py, then two more frames on the returned caches; fp32 on CPU, 8x12 latents -> 4 frames of 64x96 per call."""
+    sys.path.insert(0, ref_shim.REF)
+    import demo_utils.vae as dv
+    from oracle import vae_oracle as vo
+    w = vo.make_vae_weights(seed=0)
+    dec = dv.VAEDecoderWrapperSingle().eval()
+    missing, unexpected = dec.load_state_dict(w, strict=False)
+    assert not unexpected and set(missing) <= {"mean", "std"}, (missing, unexpected)
+    zs = vae_inputs(seed=23)[0][:, :3]
+    cache = [torch.zeros(1, t.shape[1], 2, 8 * t.shape[3] // 60, 12 * t.shape[4] // 104) for t in dv.ZERO_VAE_CACHE]
+    assert [tuple(c.shape) for c in cache] == [tuple(c.shape) for c in vo.single_zero_cache(8, 12)]
+    out = {"weights_checksum": float(sum(v.double().abs().sum() for v in w.values())), "pixels": [], "cache_sample": []}
+    with torch.no_grad():
+        for i in range(3):
+            px, cache = dec(zs[:, i:i + 1], torch.tensor([1.0 if i == 0 else 0.0]), *cache)
+            out["pixels"].append(px.clone())
+            out["cache_sample"].append([c[0, ::7, :, ::3, ::5].clone() for c in cache])
+    out["cache_shapes"] = [tuple(c.shape) for c in cache]
+    torch.save(out, os.path.join(OUT, "vae_decoder_single.pt"))
+    print("vae_decoder_single.pt", [tuple(p.shape) for p in out["pixels"]], len(cache))
+
+
 def golden_vae_encoder(ref):
     """Streaming VAE encoder (VAEEncoderWrapper, demo_utils/vae_block3.py:116-175, over wan/modules/vae.py's
     WanVAE_ encoder + conv1), fp32 on CPU, 64x96 px frames -> 8x12 latents.  Call 1: fresh cache, non-stream, 5 frames
@@ -571,7 +595,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
-    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "start_frame", "v2v", "pipeline"]
+    which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_single", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "start_frame", "v2v", "pipeline"]
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:
@@ -580,6 +604,8 @@ if __name__ == "__main__":
         golden_rolling(ref)
     if "vae" in which:
         golden_vae(ref)
+    if "vae_single" in which:
+        golden_vae_single()
     if "vae_enc" in which:
         golden_vae_encoder(ref)
     if "vae_wrapper" in which:

@@ -150,6 +150,103 @@ def decoder_wrapper_forward(w, z, feat_cache):
     return out.permute(0, 2, 1, 3, 4), feat_cache
 
 
+# ------------------------------------------------------------------------------------------------
+# VAEDecoderWrapperSingle (demo_utils/vae.py): the one-latent-frame form with explicit caches and an `is_first_frame` input
+# ------------------------------------------------------------------------------------------------
+def _single_cached_conv(x, w, name, cache):
+    """The cache idiom of demo_utils/vae.py:33-43 / :263-272 (caches are always tensors here): -> (conv output, new cache)."""
+    cache_x = x[:, :, -CACHE_T:].clone()
+    if cache_x.shape[2] < 2 and cache is not None:
+        cache_x = torch.cat([cache[:, :, -1:], cache_x], dim=2)
+    return causal_conv3d(x, w[name + ".weight"], w[name + ".bias"], (1, 1, 1), cache), cache_x
+
+
+def _single_residual_block(x, w, pre, cache_1, cache_2):
+    """ResidualBlock.forward, demo_utils/vae.py:28-47."""
+    if pre + ".shortcut.weight" in w:
+        h = causal_conv3d(x, w[pre + ".shortcut.weight"], w[pre + ".shortcut.bias"], (0, 0, 0))
+    else:
+        h = x
+    x = F.silu(rms_norm(x, w[pre + ".residual.0.gamma"]))
+    x, c1 = _single_cached_conv(x, w, pre + ".residual.2", cache_1)
+    x = F.silu(rms_norm(x, w[pre + ".residual.3.gamma"]))
+    x, c2 = _single_cached_conv(x, w, pre + ".residual.6", cache_2)
+    return x + h, c1, c2
+
+
+def _single_resample(x, w, pre, mode, is_first_frame, cache):
+    """Resample.forward + temporal_conv, demo_utils/vae.py:72-123.  On the first frame the temporal doubling is a ZERO frame in
+    front of every frame (cat([zeros, x], dim=1) through the same reshape / stack) and the cache stays what it was (:86-90);
+    otherwise time_conv over [cache | x] and the new cache is the last two input frames - [zeros, x] for a one-frame input
+    (:106-111: zeros_like, not the old cache's last frame)."""
+    b, c, t, h, wd = x.shape
+    out_cache = None
+    if mode == "upsample3d":
+        cache_x = x[:, :, -CACHE_T:].clone()
+        if cache_x.shape[2] < 2 and cache is not None:
+            cache_x = torch.cat([torch.zeros_like(cache_x), cache_x], dim=2)
+        if is_first_frame:
+            x = torch.cat([torch.zeros_like(x), x], dim=1)
+            out_cache = cache.clone()
+        else:
+            x = causal_conv3d(x, w[pre + ".time_conv.weight"], w[pre + ".time_conv.bias"], (1, 0, 0), cache)
+            out_cache = cache_x
+        x = x.reshape(b, 2, c, t, h, wd)
+        x = torch.stack((x[:, 0], x[:, 1]), 3).reshape(b, c, t * 2, h, wd)
+    t = x.shape[2]
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, wd)
+    x = F.interpolate(x.float(), scale_factor=(2.0, 2.0), mode="nearest").type_as(x)
+    x = F.conv2d(x, w[pre + ".resample.1.weight"], w[pre + ".resample.1.bias"], padding=1)
+    return x.reshape(b, t, c // 2, 2 * h, 2 * wd).permute(0, 2, 1, 3, 4), out_cache
+
+
+def decoder_single_forward(w, z, is_first_frame, feat_cache):
+    """VAEDecoderWrapperSingle.forward, demo_utils/vae.py:171-195 over VAEDecoder3d.forward :255-314.  z: [B, 1, 16, h, w];
+    feat_cache: the 32 cache tensors in execution order (zeros before the first frame, demo_utils/constant.py:6-39).  Returns
+    (pixels [B, 4, 3, 8h, 8w] in [-1, 1] - four frames on the first call as well -, the 32 new caches)."""
+    assert z.shape[1] == 1
+    fc = list(feat_cache)
+    first = bool(is_first_frame)
+    z = z.permute(0, 2, 1, 3, 4)
+    mean = torch.tensor(MEAN, dtype=z.dtype, device=z.device).view(1, 16, 1, 1, 1)
+    inv_std = 1.0 / torch.tensor(STD, dtype=z.dtype, device=z.device).view(1, 16, 1, 1, 1)
+    x = causal_conv3d(z / inv_std + mean, w["conv2.weight"], w["conv2.bias"], (0, 0, 0))
+    out, idx = [], 0
+    x, c = _single_cached_conv(x, w, "decoder.conv1", fc[idx])
+    out.append(c)
+    idx += 1
+    x, c1, c2 = _single_residual_block(x, w, "decoder.middle.0", fc[idx], fc[idx + 1])
+    out += [c1, c2]
+    idx += 2
+    x = attention_block(x, w, "decoder.middle.1")
+    x, c1, c2 = _single_residual_block(x, w, "decoder.middle.2", fc[idx], fc[idx + 1])
+    out += [c1, c2]
+    idx += 2
+    li = 0
+    for i in range(4):
+        for _ in range(3):
+            x, c1, c2 = _single_residual_block(x, w, f"decoder.upsamples.{li}", fc[idx], fc[idx + 1])
+            out += [c1, c2]
+            idx += 2
+            li += 1
+        if i != 3:
+            x, c = _single_resample(x, w, f"decoder.upsamples.{li}", "upsample3d" if i < 2 else "upsample2d", first, fc[idx])
+            if c is not None:
+                out.append(c)
+                idx += 1
+            li += 1
+    x = F.silu(rms_norm(x, w["decoder.head.0.gamma"]))
+    x, c = _single_cached_conv(x, w, "decoder.head.2", fc[idx])
+    out.append(c)
+    return x.clamp(-1, 1).permute(0, 2, 1, 3, 4), out
+
+
+def single_zero_cache(h, w, dtype=torch.float32, device="cpu"):
+    """demo_utils/constant.py:6-39 (ZERO_VAE_CACHE) for an h x w latent: 32 zero tensors [1, C, 2, H, W] in execution order."""
+    shapes = [(16, 1)] + [(384, 1)] * 11 + [(192, 2)] + [(384, 2)] * 6 + [(192, 4)] * 6 + [(96, 8)] * 7
+    return [torch.zeros(1, c, 2, h * k, w * k, dtype=dtype, device=device) for c, k in shapes]
+
+
 def decoder_conv_specs():
     """(state_dict prefix, kind, Cin, Cout) for every conv of the decoder in execution order."""
     specs = [("decoder.conv1", "c3", 16, 384)]

@@ -39,7 +39,11 @@ SIGNATURES = {
     "rtv_attn_fwd_split": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                            c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                            c_f32, c_int, c_int, c_int, c_vp, ctypes.c_size_t, c_int, c_vp],
-    "rtv_attn_set_waves": [c_int],
+    "rtv_attn_set_waves": [c_int],             # include/rtv_hip_lab.h (variant switches for tests / scripts)
+    "rtv_attn_set_skip_idle": [c_int],
+    "rtv_gemm_set_half_tail": [c_int],
+    "rtv_gemm_set_skip_idle": [c_int],
+    "rtv_lab_build": [],
     "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
                  c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "rtv_layernorm_modulate": [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp],
@@ -76,13 +80,16 @@ def build(verbose=False):
     return LIB_PATH
 
 
-def declared_symbols():
-    """Every extern "C" function declared in include/rtv_hip.h (parsed from the header)."""
+def declared_symbols(lab=True):
+    """Every extern "C" function declared in include/rtv_hip.h - the drop-in boundary - and, with `lab`, in
+    include/rtv_hip_lab.h (test / measurement hooks, not part of the boundary), parsed from the headers."""
     import re
-    hdr = os.path.join(os.path.dirname(_HERE), "include", "rtv_hip.h")
-    text = open(hdr).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rtv_[a-z0-9_]+)\s*\(", text)))
+    out = set()
+    for name in ("rtv_hip.h",) + (("rtv_hip_lab.h",) if lab else ()):
+        text = open(os.path.join(os.path.dirname(_HERE), "include", name)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out.update(re.findall(r"\b(rtv_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def load():
@@ -102,7 +109,8 @@ def load():
     for name, argtypes in sigs.items():
         fn = getattr(lib, name, None)
         if fn is None:
-            if name in SIGNATURES:
+            # RTV_LIB_PATH = an older build of the same C ABI (A/B measurements): entry points added since are simply absent
+            if name in SIGNATURES and not os.environ.get("RTV_LIB_PATH"):
                 raise RuntimeError(f"librtv_hip.so does not export {name}")
             continue
         fn.argtypes = argtypes

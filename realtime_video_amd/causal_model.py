@@ -24,7 +24,8 @@ c_vp = ctypes.c_void_p
 class _Cfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("dim", "ffn_dim", "num_heads", "num_layers", "freq_dim", "text_dim",
                                             "text_len", "in_dim", "out_dim")] + [("eps", ctypes.c_float),
-                                                                                  ("use_fp8", ctypes.c_int)]
+                                                                                  ("use_fp8", ctypes.c_int),
+                                                                                  ("max_attn_kv_splits", ctypes.c_int)]
 
 
 _LAYER_FIELDS = ("qkv_w", "qkv_b", "norm_q_w", "norm_k_w", "o_w", "o_b", "norm3_w", "norm3_b",
@@ -160,7 +161,7 @@ class CausalWanModel:
         self.use_hip_graphs = False   # replay each distinct forward (recompute / denoise step) from a captured hipGraph
         self._graphs = {}
         self._weights_version = 0     # part of the graph key: a captured graph embeds weight pointers and the launch sequence
-        self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps, 0)
+        self._cfg = _Cfg(dim, ffn_dim, num_heads, num_layers, freq_dim, text_dim, text_len, in_dim, out_dim, eps, 0, 0)
 
     # ------------------------------------------------------------------ nn.Module-ish conveniences
     def eval(self):
@@ -495,6 +496,10 @@ class CausalWanModel:
                        int(getattr(cp, "attn_kv_splits", 1)) if use_cp else 1)
             return st, (c_vp(ws_ptr), ctypes.c_size_t(ws.numel() - (ws_ptr - ws.data_ptr())), stream)
 
+        splits = int(getattr(cp, "attn_kv_splits", 1)) if use_cp else 1
+        if splits > self._cfg.max_attn_kv_splits:     # the workspace carries the split partials only once somebody asks for them
+            self._cfg.max_attn_kv_splits = splits
+            self._ws.clear()
         if self.gemm_tile_cfg in (0, 5):
             ops.ensure_gemm_workspace(u.device)
         if use_cp:

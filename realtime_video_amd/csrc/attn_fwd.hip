@@ -862,10 +862,10 @@ extern "C" int rtv_attn_debug_trace(unsigned* buf) {
 }
 #endif
 
-static int g_attn_waves = 0;     // 0 = by grid size
-static bool g_attn_lockstep = false;  // 256-row launches on the lockstep kernel only (A/B runs, tests)
-static bool g_attn_force_pp = false;  // ... on the four-phase kernel whatever the window length
-static bool g_attn_skip_idle = true;  // rtv_attn_set_skip_idle(0): A/B of the idle-wave loop (lab)
+static std::atomic<int> g_attn_waves{0};     // 0 = by grid size (include/rtv_hip_lab.h)
+static std::atomic<bool> g_attn_lockstep{false};  // 256-row launches on the lockstep kernel only (A/B runs, tests)
+static std::atomic<bool> g_attn_force_pp{false};  // ... on the four-phase kernel whatever the window length
+static std::atomic<bool> g_attn_skip_idle{true};  // rtv_attn_set_skip_idle(0): A/B of the idle-wave loop
 
 extern "C" int rtv_attn_set_skip_idle(int on) {
   g_attn_skip_idle = on != 0;
@@ -1006,13 +1006,9 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   const bool f16 = dtype == RTV_DTYPE_F16;
   const void* kerns[4] = {(const void*)attn_fwd_kernel<false, 8>, (const void*)attn_fwd_kernel<true, 8>,
                           (const void*)attn_fwd_kernel<false, 4>, (const void*)attn_fwd_kernel<true, 4>};
-  static bool attr_set[4] = {false, false, false, false};
+  static LdsAttr lds_attr[4];   // per kernel, per device
   const int ki = (waves == 4 ? 2 : 0) + (f16 ? 1 : 0);
-  if (!attr_set[ki]) {
-    hipError_t e = hipFuncSetAttribute(kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(e, "attn_fwd: hipFuncSetAttribute");
-    attr_set[ki] = true;
-  }
+  if (int st = ensure_dynamic_lds(kerns[ki], lds, &lds_attr[ki], "attn_fwd")) return st;
   const int grid = B * H * p.n_qtiles;
   double kv_avg = Lkv;  // dense; block-causal work is smaller (reported as dense upper bound / 1)
   ProfScope prof(PROF_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Lq * kv_avg * ATT_D);
@@ -1046,13 +1042,9 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
 #else
     const int lds_pp = 2 * ATT_NB * ATT_TILE_BYTES;
 #endif
-    static bool pp_attr[2] = {false, false};
+    static LdsAttr pp_attr[2];
     const void* kp = f16 ? (const void*)attn_fwd_pp_kernel<true> : (const void*)attn_fwd_pp_kernel<false>;
-    if (!pp_attr[f16]) {
-      hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp);
-      if (e != hipSuccess) return set_error(e, "attn_fwd: hipFuncSetAttribute");
-      pp_attr[f16] = true;
-    }
+    if (int st = ensure_dynamic_lds(kp, lds_pp, &pp_attr[f16], "attn_fwd")) return st;
     if (f16) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), g, t, lds_pp, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), g, t, lds_pp, (hipStream_t)stream, p);
     if (kv_splits > 1) return combine();

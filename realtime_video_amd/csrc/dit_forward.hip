@@ -76,8 +76,10 @@ static size_t carve(const rtv_dit_config* c, int F, int gh, int gw, char* base, 
     t.q8 = (uint8_t*)ws.take(c->use_fp8 ? rows * k : 0);
     t.fscale = (float*)ws.take(256);
   }
-  // a sharded call attends rows x heads <= M x H / world; with kv_splits <= world the partials of all splits fit M x H rows
-  t.attn_part_bytes = M * (size_t)c->num_heads * (128 + 2) * sizeof(float);
+  // KV-split self-attention of sharded calls, only when the configuration asks for it (97 MB per workspace at 14B
+  // that an unsharded forward never touches).  A sharded call attends rows x heads <= M x H / world; with kv_splits <= world the
+  // partials of all splits fit M x H rows.
+  t.attn_part_bytes = c->max_attn_kv_splits > 1 ? M * (size_t)c->num_heads * (128 + 2) * sizeof(float) : 0;
   t.attn_part = (float*)ws.take(t.attn_part_bytes);
   if (b) *b = t;
   if (ok) *ok = ws.ok;
@@ -282,14 +284,18 @@ static KeyWindow key_window(const rtv_dit_step* st) {
   return KeyWindow{sink ? lo : S, sink + n - first, p0, first};
 }
 
-// Self-attention of a sharded call: one launch, or the KV-split one when the step asks for it and the partials fit.
+// Self-attention of a sharded call: one launch, or the KV-split one when the step asks for it (an error when the workspace was
+// not sized for it: never a silent unsplit run).
 static int sharded_self_attn(Ctx& c, const void* q, const void* k, const void* v, void* o, int rows, int n0, int n1, int seg1_row,
                              int heads, int64_t q_rs, int64_t kv_rs, int64_t o_rs, int q_offset) {
   const rtv_dit_step* st = c.st;
   const float scale = 1.0f / sqrtf((float)c.hd);
   const int S = st->attn_kv_splits;
   const int qo = st->causal_block > 0 ? q_offset : 0;
-  if (S > 1 && rtv_attn_split_workspace_bytes(1, rows, heads, S) <= c.b.attn_part_bytes)
+  if (S > 1 && (S > c.cfg->max_attn_kv_splits || rtv_attn_split_workspace_bytes(1, rows, heads, S) > c.b.attn_part_bytes))
+    return set_error(-1, "dit: attn_kv_splits exceeds rtv_dit_config.max_attn_kv_splits / the partials do not fit the workspace "
+                         "(splits <= number of shards)");
+  if (S > 1)
     return rtv_attn_fwd_split(q, k, v, o, 1, rows, n0, n1, seg1_row, heads, c.hd, 0, q_rs, 0, kv_rs, 0, kv_rs, 0, o_rs, scale,
                               st->causal_block, qo, S, c.b.attn_part, c.b.attn_part_bytes, RTV_DTYPE_BF16, c.stream);
   return rtv_attn_fwd_win(q, k, v, o, 1, rows, n0, n1, seg1_row, heads, c.hd, 0, q_rs, 0, kv_rs, 0, kv_rs, 0, o_rs, scale,

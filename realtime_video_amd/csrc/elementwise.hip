@@ -1,6 +1,7 @@
 // HBM-bound fused elementwise kernels of the DiT block: LayerNorm+AdaLN modulation, RMSNorm,
 // RMSNorm(q,k)+3-axis RoPE+KV-cache write, modulation tables, sinusoidal embedding, (un)patchify.
-// One 256-thread workgroup per token row; every access is a 16-byte (8 x bf16) vector.
+// LayerNorm / RMSNorm: one 256-thread workgroup per token row; RoPE / cache write: two waves per row.  Every access is a 16-byte
+// (8 x bf16) vector.
 // bf16 rounding points follow the reference's eager chains (cited per kernel in include/rtv_hip.h).
 #include "rtv_common.h"
 #include "rtv_internal.h"
@@ -8,7 +9,7 @@
 namespace rtv {
 
 constexpr int EW_THREADS = 256;
-constexpr int EW_MAXC = 4;  // up to 4 x 8 elements per thread -> d <= 8192
+constexpr int EW_MAXC = 4;  // rows of up to EW_THREADS * 8 * EW_MAXC = 8192 elements (16 chunks per lane of the row's wave)
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
   v = wave_sum(v);
@@ -18,21 +19,7 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   __syncthreads();
   return red[0] + red[1] + red[2] + red[3];
 }
-__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
-  a = wave_sum(a);
-  b = wave_sum(b);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) {
-    red[w] = a;
-    red[4 + w] = b;
-  }
-  __syncthreads();
-  a = red[0] + red[1] + red[2] + red[3];
-  b = red[4] + red[5] + red[6] + red[7];
-}
-
-// ------------------------------------------------------------------ LayerNorm (+ modulation)
+// ------------------------------------------------------------------ LayerNorm (+ modulation), one 256-thread workgroup per row
 __global__ __launch_bounds__(EW_THREADS) void layernorm_modulate_kernel(
     const bf16_t* __restrict__ x, bf16_t* __restrict__ out, int d, float eps,
     const bf16_t* __restrict__ shift, const bf16_t* __restrict__ scale, int frame_stride,
@@ -104,7 +91,7 @@ __global__ __launch_bounds__(EW_THREADS) void layernorm_modulate_kernel(
   }
 }
 
-// ------------------------------------------------------------------ RMSNorm over the full channel dim
+// ------------------------------------------------------------------ RMSNorm over the full channel dim, one workgroup per row
 __global__ __launch_bounds__(EW_THREADS) void rmsnorm_kernel(const bf16_t* __restrict__ x, int ldx,
                                                              bf16_t* __restrict__ out, int ldo, int d,
                                                              float eps,
@@ -139,6 +126,26 @@ __global__ __launch_bounds__(EW_THREADS) void rmsnorm_kernel(const bf16_t* __res
   }
 }
 
+// ------------------------------------------------------------------ wave-per-row building blocks (r04: the RoPE / cache kernel)
+// Measured in round 4 (profiles/r04_row_kernels.txt): a plain copy of a [4680, 5120] bf16 tensor runs at 4.7 TB/s on this chip
+// (5.3 TB/s for 16x the rows) - that, not 8 TB/s, is what a read-once / write-once kernel of this size can reach.  LayerNorm and
+// RMSNorm were rebuilt with one WAVE per row (all of a lane's chunks in registers, DPP sums, no LDS, no barrier) and came out 5-10 %
+// SLOWER than the one-workgroup-per-row kernels above, stand-alone and inside the forward (20.8 vs 18.7 ms per block): those stay.
+// The RoPE / cache kernel (3x the bytes per row, two independent norms) does gain from the wave form: 81 -> 64 us.
+// Make the compiler forget what it knows about a register-resident chunk: the row kernels unpack their raw bf16 chunks once per
+// pass; without this the unpacked floats of the first pass are kept (CSE) for the later ones - 8 registers per chunk instead of 4 -
+// and the kernels spill or lose occupancy.
+__device__ __forceinline__ void launder(u32x4& v) {
+  uint32_t a = v[0], b = v[1], c = v[2], e = v[3];
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+  v[0] = a;
+  v[1] = b;
+  v[2] = c;
+  v[3] = e;
+}
+
+constexpr int ROWS_PER_WG = 4;
+
 // ------------------------------------------------------------------ RMSNorm(q,k) + RoPE + KV-cache write
 struct RopeArgs {
   const bf16_t* qkv;
@@ -147,7 +154,7 @@ struct RopeArgs {
   bf16_t* v_cache;
   int64_t cache_row_stride;
   int cache_row0;
-  int d, hd;
+  int M, d, hd;
   float eps;
   const bf16_t* wq;
   const bf16_t* wk;
@@ -163,54 +170,40 @@ struct RopeArgs {
   int parts;   // bit 0: process q, bit 1: process k and v (the split projection of the context-parallel overlap; 3 = all)
 };
 
-__device__ __forceinline__ void rope8(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
-                                      int pos_w, const float2* __restrict__ cs) {
-  const int half = hd >> 1;
-  const int pj0 = (col % hd) >> 1;
+// rotate the 4 complex pairs of one 8-element chunk by the (cos, sin) values in w[0..4)
+__device__ __forceinline__ void rope8(float* x, const float2* w) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    int pj = pj0 + t;
-    int pos = pj < c0 ? pos_f : (pj < c0 + c1 ? pos_h : pos_w);
-    float2 w = cs[pos * half + pj];
-    float a = x[2 * t], b = x[2 * t + 1];
-    x[2 * t] = a * w.x - b * w.y;
-    x[2 * t + 1] = a * w.y + b * w.x;
+    const float a = x[2 * t], b = x[2 * t + 1];
+    x[2 * t] = a * w[t].x - b * w[t].y;
+    x[2 * t + 1] = a * w[t].y + b * w[t].x;
   }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs a) {
-  __shared__ float red[8];
-  const int row = blockIdx.x;
+// LANE_CS: head_dim divides 512 (always on the DiT path: 128), so the column of a lane's chunks inside a head - ((lane + 64 i) * 8)
+// % hd - does not depend on i: the four (cos, sin) pairs a lane rotates with are the SAME for all of its chunks of q and of k; they
+// are fetched once per row, before the row data, and sit in 8 registers.  Otherwise they are fetched per chunk.
+//
+// TWO waves per row when K / V are processed: the q norm and the k norm are independent reductions, so one wave takes q (+ the first
+// half of the V copy), the other k (+ the second half): 40 raw registers per wave instead of 80 at d = 5120, no exchange between
+// the two.  (One wave per row held q and k: 148 registers = 3 waves per SIMD = 3072 rows in flight of 4680.)
+template <int CPL, bool LANE_CS>
+__global__ __launch_bounds__(EW_THREADS) __attribute__((amdgpu_waves_per_eu(CPL <= 10 ? 5 : 3, 8))) void qk_norm_rope_cache_kernel(RopeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const bool do_q = a.parts & 1, do_kv = a.parts & 2;   // kernel-uniform
+  const int nroles = do_kv ? 2 : 1;
+  const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWS_PER_WG + (threadIdx.x >> 6));
+  const int row = wid / nroles, role = wid - row * nroles;   // role 0: q + V chunks [0, CPL/2); role 1: k + V chunks [CPL/2, CPL)
+  if (row >= a.M) return;
   const int d = a.d;
   const int nchunks = d >> 3;
   const bf16_t* qr = a.qkv + (size_t)row * 3 * d;
-  const bf16_t* kr = qr + d;
-  const bf16_t* vr = kr + d;
-  float q[EW_MAXC][8], k[EW_MAXC][8];
-  u32x4 vraw[EW_MAXC];
-  float sq = 0.f, sk = 0.f;
-  const bool do_q = a.parts & 1, do_kv = a.parts & 2;   // kernel-uniform
-#pragma unroll
-  for (int i = 0; i < EW_MAXC; ++i) {
-    int c = threadIdx.x + i * EW_THREADS;
-    if (c < nchunks) {
-      if (do_q) {
-        unpack_bf16x8(*(const u32x4*)(qr + c * 8), q[i]);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sq += q[i][j] * q[i][j];
-      }
-      if (do_kv) {
-        unpack_bf16x8(*(const u32x4*)(kr + c * 8), k[i]);
-        vraw[i] = *(const u32x4*)(vr + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sk += k[i][j] * k[i][j];
-      }
-    }
-  }
-  block_sum2(sq, sk, red);
-  const float rq = rsqrtf(sq / (float)d + a.eps);
-  const float rk = rsqrtf(sk / (float)d + a.eps);
+  const bf16_t* vr = qr + 2 * d;
+  const bool norm = role == 1 || do_q;                // this wave normalises + rotates a vector (q or k)
+  const bf16_t* xr = role == 1 ? qr + d : qr;         // ... read from here
+  const bf16_t* wx = role == 1 ? a.wk : a.wq;
 
+  // positions of this token (wave-uniform) and the (cos, sin) pairs of this lane's columns
   const int half = a.hd >> 1;
   const int c1 = half / 3, c0 = half - 2 * c1;
   const int per_frame = a.gh * a.gw;
@@ -219,39 +212,95 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_kernel(RopeArgs
   const int rem = grow - f * per_frame;
   const int pos_h = rem / a.gw, pos_w = rem - pos_h * a.gw;
   const int pos_f = a.start_frame + f;
+  auto load_cs = [&](int col, float2* w) {
+    const int pj0 = (col % a.hd) >> 1;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pj = pj0 + t;
+      const int pos = pj < c0 ? pos_f : (pj < c0 + c1 ? pos_h : pos_w);
+      w[t] = a.rope_cs[pos * half + pj];
+    }
+  };
+  float2 cs[4];
+  if (LANE_CS && norm) load_cs(lane * 8, cs);
 
   const int gc = a.group_cols;
   size_t kv_row = gc ? (size_t)row : (size_t)(a.cache_row0 + grow);
   if (!gc && a.ring_size > 0 && (int)kv_row >= a.ring_lo)
     kv_row = (size_t)(a.ring_lo + ((int)kv_row - a.ring_lo + a.ring_shift) % a.ring_size);
-  bf16_t* qo = a.q_out + (size_t)row * (gc ? gc : d);
-  bf16_t* ko = a.k_cache + kv_row * a.cache_row_stride;
+  bf16_t* xo = role == 1 ? a.k_cache + kv_row * a.cache_row_stride : a.q_out + (size_t)row * (gc ? gc : d);
+  const int64_t x_group_stride = role == 1 ? a.kv_group_stride : a.q_group_stride;
   bf16_t* vo = a.v_cache + kv_row * a.cache_row_stride;
+
+  u32x4 raw[CPL];
+  if (norm) {
 #pragma unroll
-  for (int i = 0; i < EW_MAXC; ++i) {
-    int c = threadIdx.x + i * EW_THREADS;
-    if (c < nchunks) {
-      float wq8[8], wk8[8];
-      unpack_bf16x8(*(const u32x4*)(a.wq + c * 8), wq8);
-      unpack_bf16x8(*(const u32x4*)(a.wk + c * 8), wk8);
-      const int g = gc ? (c * 8) / gc : 0;
-      const int col = c * 8 - g * gc;
-      if (do_q) {
+    for (int i = 0; i < CPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunks) raw[i] = *(const u32x4*)(xr + c * 8);
+    }
+  }
+  // V is a plain copy into the cache; this wave moves its half of the row's chunks while its own vector is in flight
+  if (do_kv) {
+    constexpr int VH = (CPL + 1) / 2;
+    const int i0 = role * VH;
+    u32x4 vraw[VH];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) q[i][j] = round_bf16(round_bf16(q[i][j] * rq) * wq8[j]);
-        rope8(q[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
-        *(u32x4*)(qo + g * a.q_group_stride + col) = pack_bf16x8(q[i]);
-      }
-      if (do_kv) {
+    for (int i = 0; i < VH; ++i) {
+      const int c = lane + (i0 + i) * 64;
+      if (i0 + i < CPL && c < nchunks) vraw[i] = *(const u32x4*)(vr + c * 8);
+    }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) k[i][j] = round_bf16(round_bf16(k[i][j] * rk) * wk8[j]);
-        rope8(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
-        *(u32x4*)(ko + g * a.kv_group_stride + col) = pack_bf16x8(k[i]);
-        *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
+    for (int i = 0; i < VH; ++i) {
+      const int c = lane + (i0 + i) * 64;
+      if (i0 + i < CPL && c < nchunks) {
+        const int g = gc ? (c * 8) / gc : 0;
+        *(u32x4*)(vo + g * a.kv_group_stride + (c * 8 - g * gc)) = vraw[i];
       }
     }
   }
+  if (!norm) return;
+  float sx = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    if (lane + i * 64 < nchunks) {
+      float t[8];
+      unpack_bf16x8(raw[i], t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sx += t[j] * t[j];
+    }
+  }
+  const float rx = rsqrtf(wave_sum(sx) / (float)d + a.eps);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) launder(raw[i]);
+#pragma unroll
+  for (int i = 0; i < CPL; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunks) {
+      const int g = gc ? (c * 8) / gc : 0;
+      const int col = c * 8 - g * gc;
+      float2 wc[4];
+      if (!LANE_CS) load_cs(c * 8, wc);
+      float w8[8], x[8];
+      unpack_bf16x8(*(const u32x4*)(wx + c * 8), w8);
+      unpack_bf16x8(raw[i], x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = round_bf16(round_bf16(x[j] * rx) * w8[j]);
+      rope8(x, LANE_CS ? cs : wc);
+      *(u32x4*)(xo + g * x_group_stride + col) = pack_bf16x8(x);
+    }
+  }
 }
+
+// chunks per lane for a row of d elements: the smallest compiled CPL with d <= CPL * 512
+#define RTV_ROW_DISPATCH(d, CALL)      \
+  do {                                  \
+    if ((d) <= 1024) { CALL(2); }       \
+    else if ((d) <= 2048) { CALL(4); }  \
+    else if ((d) <= 5120) { CALL(10); } \
+    else { CALL(16); }                  \
+  } while (0)
 
 // ------------------------------------------------------------------ small per-forward tables
 __global__ void modulation_table_kernel(const bf16_t* __restrict__ mod, const bf16_t* __restrict__ e0,
@@ -352,6 +401,7 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   a.v_cache = (bf16_t*)v_cache;
   a.cache_row_stride = cache_row_stride;
   a.cache_row0 = cache_row0;
+  a.M = M;
   a.d = d;
   a.hd = hd;
   a.eps = eps;
@@ -370,7 +420,13 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   a.ring_shift = ring_shift;
   a.parts = parts;
   ProfScope prof(PROF_ROPE, (hipStream_t)stream, (parts == 3 ? 6.0 : parts == 1 ? 2.0 : 4.0) * M * d * 2);
-  hipLaunchKernelGGL(qk_norm_rope_cache_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+  const int waves = M * ((parts & 2) ? 2 : 1);   // two waves per row when k / v are processed (q and k normalise independently)
+  const dim3 grid((waves + ROWS_PER_WG - 1) / ROWS_PER_WG);
+#define RTV_ROPE_CALL(CPL)                                                                                                  \
+  if (512 % hd == 0) hipLaunchKernelGGL((qk_norm_rope_cache_kernel<CPL, true>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, a); \
+  else hipLaunchKernelGGL((qk_norm_rope_cache_kernel<CPL, false>), grid, dim3(EW_THREADS), 0, (hipStream_t)stream, a)
+  RTV_ROW_DISPATCH(d, RTV_ROPE_CALL);
+#undef RTV_ROPE_CALL
   return check_launch("qk_norm_rope_cache");
 }
 
@@ -432,6 +488,7 @@ int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rt
 using namespace rtv;
 
 extern "C" {
+
 
 int rtv_layernorm_modulate(const void* x, void* out, int M, int d, float eps, const void* shift,
                            const void* scale, int frame_stride, int rows_per_frame, int row_offset,

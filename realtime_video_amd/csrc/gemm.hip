@@ -98,13 +98,9 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   auto kern = gemm_kernel<F16, BM, BN, BK, WM, WN>;
-  static bool attr_set = false;
+  static LdsAttr lds_attr;   // per device
   const int lds = 2 * Cfg::STAGE_BYTES;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(e, "gemm: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  if (int st = ensure_dynamic_lds((const void*)kern, lds, &lds_attr, "gemm")) return st;
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);  // fp16 GEMMs belong to the VAE
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
   return check_launch("gemm");
@@ -134,9 +130,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     // a SMALL tail round behind one to three full rounds of 256x256 tiles (300 = 256 + 44, 540 = 2 x 256 + 28) keeps the chip
     // waiting for a few split-K units; the same problem in 128-row tiles has a well filled tail (r03: M = 1170 / 2340 / 3120,
     // profiles/r03_gemm_small_m_dispatch.log: 6-26 %)
-    const long tail256 = tiles256 % 256;
-    const bool small_tail = tiles256 > 256 && tiles256 < 4 * 256 && tail256 != 0 && tail256 * 4 < 256;
-    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < eff256 * 93 || tiles256 < 160 || small_tail))
+    const long G = device_num_cus() > 0 ? device_num_cus() : 256;   // the round size plan_split_k uses as well
+    const long tail256 = tiles256 % G;
+    const bool small_tail = tiles256 > G && tiles256 < 4 * G && tail256 != 0 && tail256 * 4 < G;
+    if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < eff256 * 93 || tiles256 * 8 < G * 5 || small_tail))
       return launch_gemm8m(p, f16, true, stream);
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
     // along K over the idle CUs, scripts/cp_gemm_shapes.py)
@@ -159,6 +156,7 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     case 5:
     case 50:
       return launch_gemm8(p, f16, true, stream);    // + split-K of the tail round = the default for large problems
+#ifdef RTV_LAB   // experimental kernels: only in the lab build (make LAB=1 -> librtv_hip_lab.so); unknown tile configs otherwise
     case 8:
       return launch_gemm4(p, f16, stream);          // 256x256, one wave per SIMD (lab: no split-K yet)
     case 81:
@@ -172,6 +170,7 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     case 90:
     case 91:
       return launch_gemm4(p, f16, stream, tile_cfg - 80);   // timing experiments (garbage results)
+#endif
     case 6:
       return launch_gemm8m(p, f16, false, stream);  // 128x256 ping-pong kernel (few-row problems), no split-K
     case 7:

@@ -36,6 +36,7 @@
 //             its last fragments of A(u) / W(u); then the reads of (u+1, k-step 0) and A(u+3) rows 0-127 into the buffer of A(u).
 // The register sets alternate with the parity of u: the tile body is instantiated per parity so that a set is a fixed group of
 // registers (data in flight into a register must never be moved by the compiler).
+#ifdef RTV_LAB   // experimental (5-7 % slower than gemm8): compiled only into the lab build, see include/rtv_hip_lab.h
 #include <type_traits>
 
 #include "gemm_core.h"
@@ -343,12 +344,8 @@ static int launch_gemm4_t(GemmParams p, hipStream_t stream) {
   p.tiles_m = (p.M + g4::BM - 1) / g4::BM;
   p.tiles_n = (p.N + g4::BN - 1) / g4::BN;
   auto kern = gemm4_kernel<F16, LAB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g4::LDS_BYTES);
-    if (e != hipSuccess) return set_error(e, "gemm4: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
+  if (int st = ensure_dynamic_lds((const void*)kern, g4::LDS_BYTES, &lds_attr, "gemm4")) return st;
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(g4::THREADS), g4::LDS_BYTES, stream, p);
   return check_launch("gemm4");
@@ -370,3 +367,4 @@ int launch_gemm4(const GemmParams& p, bool f16, hipStream_t stream, int lab) {
 }
 
 }  // namespace rtv
+#endif  // RTV_LAB

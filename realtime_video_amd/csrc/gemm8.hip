@@ -31,6 +31,7 @@
 //     caller-provided workspace and the last arriver (agent-scope release / acquire + arrival counter) sums them - for S > 2 all
 //     S slabs in index order, so the arrival order never shows in the result - and runs the epilogue;
 //   * a handful of split units (R x S <= CUs / 4) is dispatched FIRST, beside the first full tiles, instead of as a last round.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 
@@ -338,8 +339,8 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 // one K-tile further ahead: MFMA(t) stages K-tile t + 2 + group (6 pieces per wave) into buffer (t + 2 + group) % 3, then
 // waits with vmcnt(6) - everything but the pieces it has just issued - so each piece is in flight for two to three
 // intervals before the counted wait retires it, one barrier before its first reader.
-static bool g_gemm8_skip_idle = true;   // rtv_gemm_set_skip_idle(0): A/B (lab)
-static bool g_gemm8_half_tail = true;   // rtv_gemm_set_half_tail(0): K-segment tail instead (A/B)
+static std::atomic<bool> g_gemm8_skip_idle{true};   // rtv_gemm_set_skip_idle(0): A/B (include/rtv_hip_lab.h)
+static std::atomic<bool> g_gemm8_half_tail{true};   // rtv_gemm_set_half_tail(0): K-segment tail instead (A/B)
 namespace g8m {
 constexpr int BM = 128, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
@@ -515,7 +516,6 @@ constexpr int MAX_WORKSPACES = 64;
 constexpr int MAX_DEVICES = 64;
 static SplitWorkspace g_ws[MAX_WORKSPACES];
 static int g_num_ws = 0;
-static int g_num_cus[MAX_DEVICES] = {0};
 static std::mutex g_ws_mu;
 
 static int attach_workspace(bool any_stream, hipStream_t stream, void* ptr, size_t bytes) {
@@ -556,12 +556,12 @@ extern "C" int rtv_gemm_debug_timeline(unsigned long long* buf) {
 #endif
 
 extern "C" int rtv_gemm_set_half_tail(int on) {   // A/B switch (lab, tests): the half-tile tail round of gemm8
-  rtv::g_gemm8_half_tail = on != 0;
+  rtv::g_gemm8_half_tail.store(on != 0, std::memory_order_relaxed);
   return 0;
 }
 
 extern "C" int rtv_gemm_set_skip_idle(int on) {
-  rtv::g_gemm8_skip_idle = on != 0;
+  rtv::g_gemm8_skip_idle.store(on != 0, std::memory_order_relaxed);
   return 0;
 }
 
@@ -582,15 +582,10 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return set_error(-1, "gemm: cannot query the device");
   float* slabs = nullptr;
   int* counters = nullptr;
-  int G;
+  const int G = device_num_cus();
+  if (G <= 0) return set_error(-1, "gemm: cannot query the device");
   {
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    if (g_num_cus[dev] == 0) {
-      hipDeviceProp_t prop;
-      if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return set_error(-1, "gemm: cannot query the device");
-      g_num_cus[dev] = prop.multiProcessorCount;
-    }
-    G = g_num_cus[dev];
     for (int i = 0; i < g_num_ws && allow_split; ++i) {
       const SplitWorkspace& w = g_ws[i];
       if (w.device != dev) continue;
@@ -612,7 +607,7 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
   // the same parallelism without two prologues, a 256 KiB publish and a slab read per tile (tail cost 0.7-0.9 -> ~0.6 of a tile
   // time at K = 5120: o-projection 201 -> 193 us, QKV unchanged; at K = 13824 the K segments are long enough to win by 2 %:
   // profiles/r03_gemm_half_tail_ab.log); needs no workspace and keeps the unsplit summation order (bit-identical with config 4)
-  if (allow_half && g_gemm8_half_tail && R > 0 && T > R && G / R == 2 && nk <= 128) {
+  if (allow_half && g_gemm8_half_tail.load(std::memory_order_relaxed) && R > 0 && T > R && G / R == 2 && nk <= 128) {
     sp->first_unit = T - R;
     sp->tail_tiles = R;
     sp->half_tail = 1;
@@ -644,12 +639,8 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   p.tiles_m = (p.M + g8::BM - 1) / g8::BM;
   p.tiles_n = (p.N + g8::BN - 1) / g8::BN;
   auto kern = gemm8_kernel<F16, SKIP_IDLE>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8::LDS_BYTES);
-    if (e != hipSuccess) return set_error(e, "gemm8: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
+  if (int st = ensure_dynamic_lds((const void*)kern, g8::LDS_BYTES, &lds_attr, "gemm8")) return st;
   SplitArgs sp;
   int grid = 0;
   if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8::BK, allow_split, &sp, &grid, stream, /*allow_half=*/true)) return st;
@@ -663,12 +654,8 @@ static int launch_gemm8m_t(GemmParams p, bool allow_split, hipStream_t stream) {
   p.tiles_m = (p.M + g8m::BM - 1) / g8m::BM;
   p.tiles_n = (p.N + g8m::BN - 1) / g8m::BN;
   auto kern = gemm8m_kernel<F16>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, g8m::LDS_BYTES);
-    if (e != hipSuccess) return set_error(e, "gemm8m: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
+  if (int st = ensure_dynamic_lds((const void*)kern, g8m::LDS_BYTES, &lds_attr, "gemm8m")) return st;
   SplitArgs sp;
   int grid = 0;
   if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8m::BK, allow_split, &sp, &grid, stream)) return st;
@@ -689,7 +676,7 @@ int launch_gemm8(const GemmParams& p, bool f16, bool split, hipStream_t stream) 
     return set_error(-1, "gemm8: operand larger than 2 GiB");
   // the idle-wave build only where it has something to skip: the last row of tiles holds <= 128 real rows
   const int last_rows = p.M - (p.M - 1) / g8::BM * g8::BM;
-  if (g_gemm8_skip_idle && !f16 && last_rows <= 128) return launch_gemm8_t<false, true>(p, split, stream);
+  if (g_gemm8_skip_idle.load(std::memory_order_relaxed) && !f16 && last_rows <= 128) return launch_gemm8_t<false, true>(p, split, stream);
   return f16 ? launch_gemm8_t<true, false>(p, split, stream) : launch_gemm8_t<false, false>(p, split, stream);
 }
 

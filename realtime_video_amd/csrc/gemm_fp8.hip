@@ -321,12 +321,8 @@ int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, i
   if (p.gate && p.rows_per_frame <= 0) return set_error(-1, "gemm_fp8: gate needs rows_per_frame");
   p.tiles_m = (p.M + gf8::BM - 1) / gf8::BM;
   p.tiles_n = (p.N + gf8::BN - 1) / gf8::BN;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, gf8::LDS_BYTES);
-    if (e != hipSuccess) return set_error(e, "gemm_fp8: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
+  if (int st = ensure_dynamic_lds((const void*)gemm_fp8_kernel, gf8::LDS_BYTES, &lds_attr, "gemm_fp8")) return st;
   SplitArgs sp;
   int grid = 0;
   if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / gf8::BK, true, &sp, &grid, stream)) return st;

@@ -1,12 +1,28 @@
 // Host-side internals shared by the launchers: error state, launch checks, event profiling.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
+
 #include "../../include/rtv_hip.h"
+#include "../../include/rtv_hip_lab.h"
 
 namespace rtv {
 
 int set_error(int code, const char* msg);  // records message, returns code (never 0)
 int check_launch(const char* what);        // hipGetLastError -> set_error
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, DEVICE): a process that drives several GPUs (the reference's
+// GenerationSession.to(gpu) replica pattern, release_server.py:438-454) must set it on each of them.  One LdsAttr per kernel
+// remembers the devices (bit d) it has been set on; the check is one thread-local hipGetDevice per launch.
+struct LdsAttr {
+  std::atomic<uint64_t> done{0};
+};
+int ensure_dynamic_lds(const void* kernel, int bytes, LdsAttr* state, const char* what);
+
+// CUs of the current device (cached per device; 0 when the device cannot be queried).  Every dispatch rule that talks about
+// "rounds" of workgroups uses THIS number - gemm.hip's tile choice, plan_split_k, the attention split planner - not a literal 256.
+int device_num_cus();
 
 enum ProfClass { PROF_GEMM = 0, PROF_ATTN, PROF_LN, PROF_ROPE, PROF_CONV, PROF_MISC, PROF_NCLASS };
 

@@ -19,6 +19,31 @@ int set_error(int code, const char* msg) {
   return code == 0 ? -1 : code;
 }
 
+int ensure_dynamic_lds(const void* kernel, int bytes, LdsAttr* state, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return set_error(-1, "cannot query the current device");
+  const uint64_t bit = 1ull << dev;
+  if (state->done.load(std::memory_order_acquire) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return set_error((int)e, what);
+  state->done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
+int device_num_cus() {
+  static std::atomic<int> cus[64];   // zero-initialised; the CU count of a device never changes
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    n = prop.multiProcessorCount;
+    cus[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, what);
@@ -74,6 +99,14 @@ extern "C" {
 int rtv_version(void) { return 100; }
 
 const char* rtv_last_error(void) { return g_err.c_str(); }
+
+int rtv_lab_build(void) {
+#ifdef RTV_LAB
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int rtv_prof_enable(int class_mask) {
   g_prof_mask = (unsigned)class_mask;

@@ -610,12 +610,8 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
 
 static int launch_conv_halo(ConvParams p, hipStream_t stream) {
   const int tiles_x = (p.W + ch::TW - 1) / ch::TW, tiles_y = (p.H + ch::TH - 1) / ch::TH;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ch::LDS_BYTES);
-    if (e != hipSuccess) return set_error(e, "conv: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
+  if (int st = ensure_dynamic_lds((const void*)conv_halo_kernel, ch::LDS_BYTES, &lds_attr, "conv")) return st;
   ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 27 * p.Cin);
   hipLaunchKernelGGL(conv_halo_kernel, dim3(p.T * tiles_y * tiles_x * (p.Cout / 96)), dim3(ch::THREADS), ch::LDS_BYTES, stream, p,
                      tiles_x, tiles_y);
@@ -630,18 +626,14 @@ static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   const int lds = 3 * Cfg::STAGE_BYTES;
   static_assert(Cfg::NW * Cfg::TM * 32 * Cfg::TN * 64 <= 3 * Cfg::STAGE_BYTES, "epilogue image must fit the stage buffers");
   auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return set_error(e, "conv: hipFuncSetAttribute");
-    attr_set = true;
-  }
+  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
+  if (int st = ensure_dynamic_lds((const void*)kern, lds, &lds_attr, "conv")) return st;
   ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * p.kt * p.kh * p.kw * p.Cin);
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
   return check_launch("conv");
 }
 
-static bool g_conv_halo = true;   // rtv_conv_set_halo(0): A/B against conv_igemm_kernel (lab / tests)
+static std::atomic<bool> g_conv_halo{true};   // rtv_conv_set_halo(0): A/B against conv_igemm_kernel (lab / tests)
 
 int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.M <= 0) return 0;
@@ -689,7 +681,7 @@ extern "C" int rtv_conv_cl(const void* in, const void* w, const void* bias, cons
                          zeros, 0, 0, -1, -1, stream);
 }
 
-static bool g_conv_fuse_norm = true;   // rtv_conv_set_fuse_norm(0): A/B against the separate rmsnorm_silu pass (tests)
+static std::atomic<bool> g_conv_fuse_norm{true};   // rtv_conv_set_fuse_norm(0): A/B against the separate rmsnorm_silu pass (tests)
 extern "C" int rtv_conv_set_fuse_norm(int on) {
   g_conv_fuse_norm = on != 0;
   return 0;

@@ -476,8 +476,14 @@ extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, 
 /* Decode producing only pixel rows [row0, row1) (a horizontal stripe of every frame): the spatially sharded decode of
  * the context-parallel path.  Stage 0 runs on the whole latent image; stages 1-3 on the row windows of make_plan().
  * pixels: float32 [T'][3][row1-row0][8w].  row0 = 0, row1 = 8h is the plain decode. */
-extern "C" int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, int row0,
-                                   int row1, void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream_) {
+// `single`: the graph of VAEDecoderWrapperSingle (demo_utils/vae.py:150-314, the reference's one-latent-frame / TensorRT-export
+// form) instead of VAEDecoderWrapper's (demo_utils/vae_block3.py).  The two differ in the temporal upsampling only
+// (demo_utils/vae.py:72-123 vs vae_block3.py:46-67): on the first frame the single form does not skip time_conv's doubling but
+// interleaves a ZERO frame in front of every frame (cat([zeros, x], dim=1) + the same reshape / stack), leaving the time_conv cache
+// as it was, so a first call yields 4 pixel frames; and its time_conv cache after a one-frame call is [zeros, x], not
+// [where(old == 0, 0, x), x].
+static int vae_decode_impl(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, int row0, int row1,
+                           void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream_, bool single) {
   if (!w || !z || !arena || !pixels) return set_error(-1, "vae_decode: null argument");
   if (T <= 0) return 0;
   if ((h * wd) % 8) return set_error(-1, "vae_decode: h*w must be a multiple of 8");
@@ -536,12 +542,28 @@ extern "C" int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int 
       if (s < 2) {  // upsample3d: temporal doubling through time_conv, skipped for the very first frame
         const size_t sl = (size_t)H * W * cout;
         uint16_t* buf = c.cat(ci);
-        if (!is_first) {
+        if (is_first && single) {   // demo_utils/vae.py:112-123 with is_first_frame: frames [0, x_0, 0, x_1, ...], cache untouched
+          for (int t = 0; t < Tn; ++t) {
+            if (hipMemsetAsync(free_[0] + (size_t)(2 * t) * sl, 0, sl * 2, stream) != hipSuccess ||
+                hipMemcpyAsync(free_[0] + (size_t)(2 * t + 1) * sl, x + (size_t)t * sl, sl * 2, hipMemcpyDeviceToDevice, stream) !=
+                    hipSuccess)
+              return set_error(-1, "vae_decode: memset / memcpy failed");
+          }
+          x = free_[0];
+          Tn *= 2;
+          nb = 0;
+          for (int i = 0; i < 4; ++i)
+            if (c.act(i) != x) free_[nb++] = c.act(i);
+        } else if (!is_first) {
           if (hipMemcpyAsync(buf + 2 * sl, x, (size_t)Tn * sl * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess)
             return set_error(-1, "vae_decode: memcpy failed");
           RTV_TRY(rtv_conv_cl(buf, w->time_conv[s].w, w->time_conv[s].b, nullptr, 0, free_[0], cout, Tn, H, W, cout,
                               2 * cout, 3, 1, 1, 0, cout, c.zeros(), stream));
-          if (Tn == 1) {
+          if (Tn == 1 && single) {   // demo_utils/vae.py:106-111: cache <- [zeros, x]
+            if (hipMemsetAsync(buf, 0, sl * 2, stream) != hipSuccess ||
+                hipMemcpyAsync(buf + sl, buf + 2 * sl, sl * 2, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+              return set_error(-1, "vae_decode: memset / memcpy failed");
+          } else if (Tn == 1) {
             hipLaunchKernelGGL(upsample_cache_t1_kernel, dim3(1024), dim3(256), 0, stream, (f16_t*)buf, (int64_t)sl);
             RTV_TRY(check_launch("upsample_cache_t1"));
           } else {
@@ -581,9 +603,19 @@ extern "C" int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int 
   return 0;
 }
 
+extern "C" int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, int row0,
+                                   int row1, void* arena, size_t arena_bytes, void* pixels, rtv_stream_t stream) {
+  return vae_decode_impl(w, z, T, h, wd, first, row0, row1, arena, arena_bytes, pixels, stream, false);
+}
+
 extern "C" int rtv_vae_decode(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, void* arena,
                               size_t arena_bytes, void* pixels, rtv_stream_t stream) {
-  return rtv_vae_decode_rows(w, z, T, h, wd, first, 0, h << 3, arena, arena_bytes, pixels, stream);
+  return vae_decode_impl(w, z, T, h, wd, first, 0, h << 3, arena, arena_bytes, pixels, stream, false);
+}
+
+extern "C" int rtv_vae_decode_single(const rtv_vae_weights* w, const void* z, int h, int wd, int is_first_frame, void* arena,
+                                     size_t arena_bytes, void* pixels, rtv_stream_t stream) {
+  return vae_decode_impl(w, z, 1, h, wd, is_first_frame ? 1 : 0, 0, h << 3, arena, arena_bytes, pixels, stream, true);
 }
 
 // ====================================================================================== streaming encoder

@@ -46,13 +46,15 @@ class _ExchangeChoice:
         return True
 
 
-def attn_kv_splits_for(world, num_heads, q_tiles=19, cus=256):
+def attn_kv_splits_for(world, num_heads, q_tiles=19, cus=None):
     """How many key ranges a context-parallel rank's self-attention launch should be cut into (ContextParallel(attn_kv_splits=)).
     One rank's launch has num_heads x q_tiles / world workgroups (either exchange), one per CU at a time: rounds of `cus`.  S
     ranges make S x as many workgroups of 1/S the length, + ~6 % per extra range for the merge kernel and the per-workgroup
     prologue (profiles/r03_attn_kv_split_ab.log).  14B (40 heads): 2 / 4 / 2 ranges at 2 / 4 / 8 ranks; 1 rank: 1."""
     if world <= 1:
         return 1
+    if cus is None:     # the device's real CU count (the same number the GEMM dispatch and plan_split_k use), 256 without a GPU
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
     g = max(1, num_heads * q_tiles // world)
     cost = {s: -(-g * s // cus) / s * (1 + 0.06 * (s - 1)) for s in (1, 2, 4) if s <= world}
     return min(cost, key=lambda s: (cost[s], s))

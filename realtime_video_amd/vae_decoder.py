@@ -50,6 +50,9 @@ _lib.EXTRA_SIGNATURES.update({
     "rtv_conv_cl_win": [c_vp, c_vp, c_vp, c_vp, ctypes.c_int, c_vp, ctypes.c_int] + [ctypes.c_int] * 10 + [c_vp]
                        + [ctypes.c_int] * 4 + [c_vp],
     "rtv_vae_decode_rows": [ctypes.POINTER(_VaeWeights), c_vp] + [ctypes.c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp, c_vp],
+    "rtv_vae_decode_single": [ctypes.POINTER(_VaeWeights), c_vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_vp, ctypes.c_size_t,
+                              c_vp, c_vp],
+    "rtv_conv_set_halo": [ctypes.c_int],
     "rtv_vae_cache_slot_rows": [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_size_t)] + [ctypes.POINTER(ctypes.c_int)] * 4,
 })
 
@@ -281,6 +284,49 @@ class VAEDecoderWrapper:
                   c_vp(torch.cuda.current_stream().cuda_stream))
         cache = list(feat_cache) if not first else self._cache_views(arena, base, h, w)
         return pixels.unsqueeze(0), cache
+
+    __call__ = forward
+
+
+class VAEDecoderWrapperSingle(VAEDecoderWrapper):
+    """Mirror of the reference's `VAEDecoderWrapperSingle` (demo_utils/vae.py:150-195, its TensorRT-export / one-latent-frame
+    form): `forward(z[B, 1, 16, h, w], is_first_frame, *feat_cache)` -> `(pixels[B, 4, 3, 8h, 8w] in [-1, 1], feat_cache)` with
+    the 32 feature caches ALWAYS present as tensors `[1, C, 2, H, W]` in execution order (zeros before the first frame:
+    `zero_cache(h, w)` = demo_utils/constant.py:6-39 at another latent size) and the first frame marked by the caller.  Same
+    weights, same kernels and arena as `VAEDecoderWrapper`; the graph differs in the temporal upsampling only
+    (`rtv_vae_decode_single`, include/rtv_hip.h): four frames also on the first call.  The returned caches are views of the
+    stream's arena, updated in place by the next call (as for VAEDecoderWrapper: clone a slot to keep a snapshot)."""
+
+    NUM_CACHES = 32
+
+    def zero_cache(self, h, w, dtype=torch.float16):
+        shapes = [(16, 1)] + [(384, 1)] * 11 + [(192, 2)] + [(384, 2)] * 6 + [(192, 4)] * 6 + [(96, 8)] * 7
+        return [torch.zeros(1, c, 2, h * k, w * k, dtype=dtype, device=self.device) for c, k in shapes]
+
+    def forward(self, z, is_first_frame, *feat_cache):
+        if self._w is None:
+            raise RuntimeError("weights not loaded")
+        if not z.is_cuda:
+            raise RuntimeError("realtime_video_amd.VAEDecoderWrapperSingle needs GPU tensors (no CPU fallback)")
+        B, T, C, h, w = z.shape
+        assert T == 1                                                   # demo_utils/vae.py:180
+        if B != 1 or C != 16:
+            raise NotImplementedError("VAE decoder: batch 1, 16 latent channels")
+        if len(feat_cache) != self.NUM_CACHES or any(c is None for c in feat_cache):
+            raise ValueError(f"VAEDecoderWrapperSingle takes its {self.NUM_CACHES} feature caches as tensors (zero_cache(h, w) "
+                             "before the first frame)")
+        if self.row_range(h) != (0, 8 * h):
+            raise NotImplementedError("the single-frame form decodes whole frames")
+        first = bool(is_first_frame.item() if torch.is_tensor(is_first_frame) else is_first_frame)
+        cache = list(feat_cache) + [None] * (55 - self.NUM_CACHES)
+        arena, base = self._arenas.lookup(cache, (h, w), lambda: self._new_arena(h, w),
+                                          lambda a, b: self._cache_views(a, b, h, w))
+        zz = z[0].to(torch.float16).contiguous()
+        pixels = torch.empty((4, 3, 8 * h, 8 * w), dtype=torch.float32, device=z.device)
+        _lib.call("rtv_vae_decode_single", ctypes.byref(self._w), c_vp(zz.data_ptr()), h, w, int(first),
+                  c_vp(arena.data_ptr() + base), ctypes.c_size_t(arena.numel() - base), c_vp(pixels.data_ptr()),
+                  c_vp(torch.cuda.current_stream().cuda_stream))
+        return pixels.unsqueeze(0), cache[:self.NUM_CACHES]
 
     __call__ = forward
 

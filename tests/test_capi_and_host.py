@@ -17,6 +17,13 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.rtv_version() >= 100
+    # the drop-in boundary (include/rtv_hip.h) carries no variant switches: those live in include/rtv_hip_lab.h, and the product
+    # library holds no experimental kernels
+    boundary = _lib.declared_symbols(lab=False)
+    assert not [s_ for s_ in boundary if "_set_" in s_ and s_ not in ("rtv_gemm_set_workspace", "rtv_gemm_set_stream_workspace")]
+    assert "rtv_attn_set_waves" in syms and "rtv_attn_set_waves" not in boundary
+    if not os.environ.get("RTV_LIB_PATH"):
+        assert lib.rtv_lab_build() == 0
     lib.rtv_dit_workspace_bytes.restype = ctypes.c_size_t
     lib.rtv_vae_arena_bytes.restype = ctypes.c_size_t
     lib.rtv_vae_arena_bytes.argtypes = [ctypes.c_int, ctypes.c_int]

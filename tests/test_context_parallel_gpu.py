@@ -101,3 +101,39 @@ def test_two_process_context_parallel_session_equals_single_process(exchange, ba
             assert torch.equal(k, ref_k[:, :, rank * hn:(rank + 1) * hn])
         else:
             assert torch.equal(k, ref_k)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["heads", "rows"])
+def test_eight_rank_bench_launcher_path_equals_single_process(exchange):
+    """Eight-rank readiness without an eight-GPU node: `bench.py --gpus 8` through ITS OWN launcher path
+    (re-exec under torch.distributed.run, one process per rank, ContextParallel + row-sharded VAE decode + pixel all-gather +
+    frame delivery), all ranks sharing cuda:0 with gloo collectives (RTV_BENCH_SHARED_GPU=1), on the test-rig model (8 heads: one
+    head per rank under the head exchange; 585 token rows per rank).  The last block's latents must be bit-identical with the
+    single-process run of the same command.  attn_kv_splits 1 and GEMM tile config 4 (no split-K): the default dispatch splits K
+    on tail tiles by the launch's tile count, i.e. by the shard's row count, which re-associates fp32 sums (scripts/
+    gemm_shard_identity.py: N = 2048, K = 1024 at M = 4680 vs its shards) - with it sharded and unsharded agree to one-ulp bf16
+    flips only (tests/test_dit_gpu.py::test_full_width_layer_context_parallel_equals_unsharded states that tolerance)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RTV_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+
+    def run(n):
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--model", "tiny", "--steps", "1", "--warmup", "2",
+               "--no-cpu-baseline", "--cp-exchange", exchange, "--cp-attn-splits", "1", "--profile-classes", "none",
+               "--gemm-tile-cfg", "4"]
+        res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=800, cwd=root)
+        assert res.returncode == 0, res.stderr[-3000:]
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+
+    one, eight = run(1), run(8)
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and one["n_gpus"] == 1
+    assert "cp8" in eight["config"]["parallelism"]
+    a, b = one["config"]["last_block_latents_checksum"], eight["config"]["last_block_latents_checksum"]
+    assert a["shape"] == b["shape"] == [1, 3, 16, 60, 104]
+    assert a["sha256_bf16"] == b["sha256_bf16"], (a, b)

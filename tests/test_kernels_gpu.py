@@ -537,7 +537,15 @@ def test_attention_kv_split_matches_unsplit(ops, Lq, Lkv, H, splits, waves):
 def test_gemm_one_wave_per_simd_config_is_bit_identical(ops):
     """Tile config 8 (gemm4.hip: four waves, 128 x 128 per wave, A by LDS DMA, W through registers) against the production
     ping-pong kernel (config 4) on the layer shapes and ragged ones: same K order per accumulator, same epilogue - bit-identical;
-    K must be a multiple of 128 (the K loop runs in pairs of tiles)."""
+    K must be a multiple of 128 (the K loop runs in pairs of tiles).  An experimental kernel: present in the lab build only
+    (make LAB=1, RTV_LIB_PATH=.../librtv_hip_lab.so); the product library must REJECT the configuration (a mistyped
+    tile config must not return numbers from a timing experiment)."""
+    from realtime_video_amd import _lib
+    if not _lib.load().rtv_lab_build():
+        for cfg in (8, 81, 86, 91):
+            with pytest.raises(RuntimeError):
+                ops.gemm(_randn(256, 256, seed=1), _randn(256, 256, seed=2), tile_cfg=cfg)
+        return
     for M, N, K, act in ((4680, 5120, 1024, 1), (585, 1536, 5120, 0), (300, 520, 256, 2), (257, 264, 128, 0), (1000, 2048, 1664, 1)):
         a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
         r = _randn(M, N, seed=4)

@@ -248,6 +248,39 @@ def test_streaming_decoder_matches_reference_golden(golden):
     assert px.shape[1] == 9 and max_abs(px.cpu(), g["pixels"][0]) <= 3e-2
 
 
+def test_single_frame_decoder_wrapper_matches_reference_golden(golden):
+    """`VAEDecoderWrapperSingle` (demo_utils/vae.py:150-195: one latent frame per call, `is_first_frame` given by the caller, the 32
+    caches always tensors) against the golden minted from the reference's own module: first frame on zero caches - four frames out,
+    the zero-interleaved temporal doubling - then two frames on the returned caches, one of them fed back as CLONED tensors.  Same
+    stated tolerance as the block wrapper: within 2x the eager-fp16 oracle's error (+ floor), hard cap 5e-2, mean-abs 2e-3."""
+    from oracle import vae_oracle as vo
+    from oracle.make_golden import vae_inputs
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapperSingle
+    g = golden("vae_decoder_single.pt")
+    dec = VAEDecoderWrapperSingle(DEV)
+    dec.load_state_dict(vo.make_vae_weights(seed=0))
+    w16 = {k: v.half().to(DEV) for k, v in vo.make_vae_weights(seed=0).items()}
+    zs = vae_inputs(seed=23)[0][:, :3]
+    cache = dec.zero_cache(8, 12)
+    cache16 = vo.single_zero_cache(8, 12, torch.float16, DEV)
+    for i in range(3):
+        first = torch.tensor([1.0 if i == 0 else 0.0], device=DEV, dtype=torch.float16)     # vae_torch2trt.py:167,174
+        if i == 2:
+            cache = [c.clone() for c in cache]
+        px, cache = dec(zs[:, i:i + 1].half().to(DEV), first, *cache)
+        ref = g["pixels"][i]
+        assert px.shape == ref.shape == (1, 4, 3, 64, 96) and px.dtype == torch.float32 and len(cache) == 32
+        px16, cache16 = vo.decoder_single_forward(w16, zs[:, i:i + 1].half().to(DEV), i == 0, cache16)
+        err, err16 = max_abs(px.cpu(), ref), max_abs(px16.float().cpu(), ref)
+        assert err <= max(2 * err16, 2e-2) and err <= 5e-2, (i, err, err16)
+        assert float((px.cpu() - ref).abs().mean()) <= 2e-3, i
+        for c, gs, shp in zip(cache, g["cache_sample"][i], g["cache_shapes"]):
+            assert tuple(c.shape) == shp
+            assert max_abs(c[0, ::7, :, ::3, ::5].float().cpu(), gs) <= 2e-2 + 2e-2 * float(gs.abs().max()), i
+    with pytest.raises(ValueError):
+        dec(zs[:, :1].half().to(DEV), True, *([None] * 32))
+
+
 def test_cloned_feature_cache_continues_the_stream_and_foreign_cache_is_refused():
     """The cache list is a set of views into one arena that the next call updates in place.  A snapshot of it (every
     slot cloned, as a caller keeping state across requests would) must continue the stream bit-identically, and a cache

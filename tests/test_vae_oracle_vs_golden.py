@@ -27,6 +27,26 @@ def test_vae_decoder_streaming_matches_reference(golden):
             assert max_abs(c[0, ::7, :, ::3, ::5], gs) <= 1e-4
 
 
+def test_vae_decoder_single_frame_form_matches_reference(golden):
+    """oracle decoder_single_forward vs the reference's VAEDecoderWrapperSingle (demo_utils/vae.py:150-195): first frame on zero
+    caches (4 frames: the zero-interleaved temporal doubling), then two frames on the returned caches."""
+    g = golden("vae_decoder_single.pt")
+    w = vo.make_vae_weights(seed=0)
+    zs = vae_inputs(seed=23)[0][:, :3]
+    cache = vo.single_zero_cache(8, 12)
+    for i in range(3):
+        px, cache = vo.decoder_single_forward(w, zs[:, i:i + 1], i == 0, cache)
+        assert px.shape == g["pixels"][i].shape == (1, 4, 3, 64, 96)
+        assert max_abs(px, g["pixels"][i]) <= 1e-4, i
+        assert len(cache) == 32
+        for c, gs in zip(cache, g["cache_sample"][i]):
+            assert max_abs(c[0, ::7, :, ::3, ::5], gs) <= 1e-4, i
+    assert [tuple(c.shape) for c in cache] == g["cache_shapes"]
+    # the two wrappers are different graphs on the first frame: the single form's real frame sees a bias-only frame behind it
+    px3, _ = vo.decoder_wrapper_forward(w, zs[:, :1], [None] * 55)
+    assert px3.shape[1] == 1 and max_abs(px3[:, 0], g["pixels"][0][:, 3]) > 1e-3
+
+
 def test_decoder_conv_inventory():
     specs = vo.decoder_conv_specs()
     assert sum(k in ("c3", "t3") for _, k, _, _ in specs) == 32 and sum(k == "c1" for _, k, _, _ in specs) == 1
