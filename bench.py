@@ -13,7 +13,10 @@ import os
 import sys
 import time
 
-import torch
+# RCCL between processes needs dmabuf IPC on this platform (the driver's environment exports it; keep it if somebody does not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -25,6 +28,7 @@ MODELS = {
     "tiny": dict(dim=1024, ffn_dim=2048, num_heads=8, num_layers=2, name="TEST RIG (INVALID as a result): 2-layer d=1024 H=8"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md)
+HBM_PEAK_TBPS = 8.0        # HBM3E, MI355X (MI355X_MICROARCH.md)
 MFMA_SUSTAINED_FP8_TFLOPS = 4350.0  # v_mfma_f32_32x32x64_f8f6f4 loop, random e4m3 operands (scripts/micro/fp8_mfma.hip)
 MFMA_SUSTAINED_TFLOPS = 1770.0  # measured: MFMA-only loop, random operands, clock settles at 1.78 GHz (profiles/r01_mfma_peak.txt)
 
@@ -132,10 +136,14 @@ def main():
     ap.add_argument("--denoising-steps", type=int, default=4)
     ap.add_argument("--no-vae", action="store_true", help="diagnostic only: skips the VAE (result is flagged invalid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-classes", default="gemm,attn,conv",
-                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm,attn,conv' (the roofline kernel, "
-                         "the attention kernels and the VAE convolutions, default), 'all' (diagnostic: every launch, costs a few "
-                         "%% of throughput) or 'none'")
+    ap.add_argument("--profile-classes", default="gemm,attn,conv,layernorm,rope",
+                    help="kernel classes bracketed with hipEvents inside the timed region: 'gemm,attn,conv,layernorm,rope' (the roofline "
+                         "kernel, the attention kernels, the VAE convolutions and the HBM-bound row kernels, default), 'all' "
+                         "(diagnostic: every launch) or 'none'")
+    ap.add_argument("--profile-stride", default="gemm=13,attn=5,layernorm=11,rope=7,conv=3",
+                    help="bracket only every n-th launch of a class (an event pair costs the launch stream ~2.5 us per record: "
+                         "bracketing all ~2.4 k GEMM launches of a block cost it ~12 ms, the ~940 row-kernel launches 9 ms - "
+                         "profiles/r04_bench_bracket_overhead.txt); class times are the sampled times scaled by work")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
                          "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
@@ -305,6 +313,9 @@ def main():
         sess.generate_block()
     barrier()
     ops.prof_reset()
+    strides = {k: int(v) for k, v in (kv.split("=") for kv in args.profile_stride.split(",") if kv)}
+    for cls in ("gemm", "attn", "layernorm", "rope", "conv", "misc"):
+        ops.prof_set_stride(cls, 1 if args.profile_classes == "all" else strides.get(cls, 1))
     ops.prof_enable(args.profile_classes != "none",
                     None if args.profile_classes == "all" else [c for c in args.profile_classes.split(",") if c != "none"])
     wr.on = True
@@ -387,10 +398,10 @@ def main():
             "dit_ms_per_denoise_step": sum(step_ms) / max(1, len(step_ms)),        # BASELINE.json "per-step DiT latency"
             "dit_ms_per_recompute_forward": sum(recompute_ms) / max(1, len(recompute_ms)) if recompute_ms else None,
             # kernel-class times exist only for the classes bracketed with events (--profile-classes; 'all' = diagnostic)
-            "dit_ms_per_forward": ((prof["gemm"]["ms"] + prof["attn"]["ms"] + prof["layernorm"]["ms"] + prof["rope"]["ms"]
-                                    + prof["misc"]["ms"]) / (args.steps * fwd_per_block)
+            "dit_ms_per_forward": ((prof["gemm"]["ms_class"] + prof["attn"]["ms_class"] + prof["layernorm"]["ms_class"]
+                                    + prof["rope"]["ms_class"] + prof["misc"]["ms_class"]) / (args.steps * fwd_per_block)
                                    if args.profile_classes == "all" else None),
-            "kernel_ms_per_block": {k: v["ms"] / args.steps for k, v in prof.items() if v["launches"] > 0},
+            "kernel_ms_per_block": {k: v["ms_class"] / args.steps for k, v in prof.items() if v["launches"] > 0},
             # host side of a block: the session loop's wall time, the part of it spent blocked on the previous block's frames
             # (a wait on the GPU, not work) and the rest = Python + ctypes launch issue (6 ms under --hipgraph)
             "host_ms_per_block": host_ms,
@@ -408,10 +419,24 @@ def main():
             "traffic_launches_sampled": traffic_n,
             "algorithmic_bytes_per_launch": None if args.fp8 else gemm_algorithmic_bytes(mc),
             "frac_of_sustained_mfma": achieved / (MFMA_SUSTAINED_FP8_TFLOPS if args.fp8 else MFMA_SUSTAINED_TFLOPS),
-            "launches": gm["launches"],
+            "launches": gm["launches"],                  # bracketed with events (every `sample_stride`-th launch of the class)
+            "launches_in_timed_region": gm["seen_launches"],
+            "sample_stride": 1 if args.profile_classes == "all" else strides.get("gemm", 1),
             "avg_launch_ms": gm["ms"] / max(gm["launches"], 1),
             "attention_TFLOPs": prof["attn"]["work"] / (prof["attn"]["ms"] * 1e-3) / 1e12 if prof["attn"]["ms"] > 0 else None,
             "conv_TFLOPs": prof["conv"]["work"] / (prof["conv"]["ms"] * 1e-3) / 1e12 if prof["conv"]["ms"] > 0 else None,
+            # the other kernel classes against THEIR roofline (same event brackets; only the classes named in --profile-classes):
+            # attention / VAE conv against the dense MFMA peak, the row kernels against 8 TB/s of HBM (algorithmic bytes; a plain
+            # copy of the same tensors reaches 0.59-0.67 of that peak on this chip, profiles/r04_row_kernels.txt)
+            "other_kernels": {
+                name: ({"bound": "mfma", "achieved_TFLOPs": v["work"] / (v["ms"] * 1e-3) / 1e12,
+                        "frac": v["work"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "ms_per_block": v["ms_class"] / args.steps,
+                        "launches_bracketed": v["launches"], "launches": v["seen_launches"]}
+                       if name in ("attn", "conv") else
+                       {"bound": "hbm", "achieved_TBps": v["work"] / (v["ms"] * 1e-3) / 1e12,
+                        "frac": v["work"] / (v["ms"] * 1e-3) / 1e12 / HBM_PEAK_TBPS, "ms_per_block": v["ms_class"] / args.steps,
+                        "launches_bracketed": v["launches"], "launches": v["seen_launches"]})
+                for name, v in prof.items() if name in ("attn", "conv", "layernorm", "rope") and v["ms"] > 0},
         },
     }
     if not args.no_cpu_baseline:

@@ -41,6 +41,12 @@ const char* rtv_last_error(void);
 int rtv_prof_enable(int class_mask);
 int rtv_prof_read(int cls, double* total_ms, int64_t* launches, double* total_work);
 int rtv_prof_reset(void);
+/* Sampled bracketing: an event pair costs the launch stream a few microseconds, which matters for 20 us kernels and for thousands
+ * of launches per block.  rtv_prof_set_stride(cls, n): bracket every n-th launch of class cls (default 1 = every launch);
+ * rtv_prof_read_seen: ALL launches of the (enabled) class and their summed work since the last reset - the sampled time of
+ * rtv_prof_read scales to the class by seen_work / sampled_work. */
+int rtv_prof_set_stride(int cls, int stride);
+int rtv_prof_read_seen(int cls, int64_t* launches, double* work);
 
 /* ---- K1/K2/K3: attention backend --------------------------------------------------------
  * Replaces wan/modules/attention.py:150-212 `attention(q,k,v,...)` (and the sage custom op

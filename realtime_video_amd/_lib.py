@@ -27,6 +27,8 @@ SIGNATURES = {
     "rtv_prof_read": [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64),
                       ctypes.POINTER(ctypes.c_double)],
     "rtv_prof_reset": [],
+    "rtv_prof_set_stride": [c_int, c_int],
+    "rtv_prof_read_seen": [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double)],
     "rtv_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
                      c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                      c_f32, c_int, c_int, c_int, c_vp],

@@ -50,11 +50,23 @@ def prof_reset():
     _lib.call("rtv_prof_reset")
 
 
+def prof_set_stride(cls, stride):
+    """Bracket only every `stride`-th launch of a class (an event pair costs the stream a few microseconds; prof_read then
+    carries the sampled launches and `seen_*` all of them)."""
+    _lib.call("rtv_prof_set_stride", PROF_CLASSES[cls] if isinstance(cls, str) else int(cls), int(stride))
+
+
 def prof_read(cls):
+    """-> ms / launches / work of the BRACKETED launches, seen_launches / seen_work of all launches of the class, and `ms_class` =
+    the bracketed time scaled to the whole class by work."""
+    c = PROF_CLASSES[cls] if isinstance(cls, str) else int(cls)
     ms, n, work = ctypes.c_double(0), ctypes.c_int64(0), ctypes.c_double(0)
-    _lib.call("rtv_prof_read", PROF_CLASSES[cls] if isinstance(cls, str) else int(cls),
-              ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work))
-    return {"ms": ms.value, "launches": n.value, "work": work.value}
+    _lib.call("rtv_prof_read", c, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(work))
+    sn, swork = ctypes.c_int64(0), ctypes.c_double(0)
+    _lib.call("rtv_prof_read_seen", c, ctypes.byref(sn), ctypes.byref(swork))
+    scale = swork.value / work.value if work.value > 0 else 1.0
+    return {"ms": ms.value, "launches": n.value, "work": work.value, "seen_launches": sn.value, "seen_work": swork.value,
+            "ms_class": ms.value * scale}
 
 
 # --------------------------------------------------------------------------------------- attention
