@@ -23,6 +23,10 @@ int rtv_attn_set_waves(int waves);
 /* gemm8 (256x256 ping-pong GEMM): tail round as 128x256 half tiles (default 1) or as K segments with an fp32 slab reduction (0).
  * Half tiles keep the unsplit summation order (bit-identical with tile config 4). */
 int rtv_gemm_set_half_tail(int on);
+/* gemm8: where it removes the tail round (ffn-in at M = 4680), a ragged last row of tiles (<= 128 real rows) runs as 128 x 512 strips
+ * in front of the tile grid (default 1) or stays in the grid as half-empty 256-row tiles (0).  Bit-identical per output element
+ * (full K through the 128-row body); the strips also replace that shape's split-K units, whose sums are re-associated. */
+int rtv_gemm_set_ragged_strips(int on);
 /* gemm8: waves whose 128 rows all lie beyond M run an idle loop (default 1) or the full K loop on clamped rows (0).  Bit-identical. */
 int rtv_gemm_set_skip_idle(int on);
 /* VAE decoder: RMS_norm + SiLU fused into the producing 96-channel conv (default 1) or as a separate pass (0); the two differ by

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rtv_attn_set_skip_idle": [c_int],
     "rtv_gemm_set_half_tail": [c_int],
     "rtv_gemm_set_skip_idle": [c_int],
+    "rtv_gemm_set_ragged_strips": [c_int],
     "rtv_lab_build": [],
     "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
                  c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],

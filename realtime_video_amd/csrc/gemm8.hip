@@ -64,8 +64,25 @@ __device__ __forceinline__ void gemm8m_body(const GemmParams& p, const SplitArgs
 template <bool F16, bool SKIP_IDLE>
 __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, SplitArgs sp) {
   using namespace g8;
-  // ---- tail round as half tiles (sp.half_tail): block ids >= first_unit (after the split_first rotation) are 128 x 256 units
   int bid0 = blockIdx.x;
+  // ---- ragged last row of tiles as 128 x 512 strips (sp.pair_units): the FIRST block ids - equal units that start together, then
+  //      the tile grid runs in lockstep as before (a workgroup that finishes a cheaper unit in the middle of a round runs ahead of
+  //      the tiles it shares A / W panels with and streams them alone: profiles/r04_gemm_ragged_row.log)
+  if (sp.pair_units) {
+    if (bid0 < sp.pair_pad) {
+      if (bid0 >= sp.pair_units) return;   // padding id
+#pragma unroll 1
+      for (int j = 0; j < 2; ++j) {
+        const int tn = 2 * bid0 + j;
+        if (tn >= p.tiles_n) break;
+        if (j) __syncthreads();            // the first half tile's epilogue has left the LDS
+        gemm8m_body<F16>(p, sp, sp.pair_m0, tn * BN, 0, 0, -1, 0, p.K / BK, false);
+      }
+      return;
+    }
+    bid0 -= sp.pair_pad;
+  }
+  // ---- tail round as half tiles (sp.half_tail): block ids >= first_unit (after the split_first rotation) are 128 x 256 units
   if (sp.half_tail) {
     const int nhu = 2 * sp.tail_tiles;
     if (sp.split_first) bid0 = bid0 < nhu ? sp.first_unit + bid0 : bid0 - nhu;
@@ -112,7 +129,6 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   const int in_group = tile_id - group * per_group;
   const int m0 = (first_m + in_group % gm) * BM;
   const int n0 = (in_group / gm) * BN;
-
   // ---- DMA geometry: a half-tile is 2 wave-wide pieces per wave; piece j of wave w fills rows j*64 + w*8 .. +8
   //      (lane -> row + lane/8, chunk slot lane%8), source chunk pre-swizzled.  BYTE offsets at k = 0.
   uint32_t src_off[4][2];  // [A0, A1, W0, W1][j]
@@ -341,6 +357,7 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
 // intervals before the counted wait retires it, one barrier before its first reader.
 static std::atomic<bool> g_gemm8_skip_idle{true};   // rtv_gemm_set_skip_idle(0): A/B (include/rtv_hip_lab.h)
 static std::atomic<bool> g_gemm8_half_tail{true};   // rtv_gemm_set_half_tail(0): K-segment tail instead (A/B)
+static std::atomic<bool> g_gemm8_ragged_strips{true}; // rtv_gemm_set_ragged_strips(0): the ragged last row of tiles stays in the tile grid
 namespace g8m {
 constexpr int BM = 128, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
@@ -560,6 +577,11 @@ extern "C" int rtv_gemm_set_half_tail(int on) {   // A/B switch (lab, tests): th
   return 0;
 }
 
+extern "C" int rtv_gemm_set_ragged_strips(int on) {
+  rtv::g_gemm8_ragged_strips.store(on != 0, std::memory_order_relaxed);
+  return 0;
+}
+
 extern "C" int rtv_gemm_set_skip_idle(int on) {
   rtv::g_gemm8_skip_idle.store(on != 0, std::memory_order_relaxed);
   return 0;
@@ -577,7 +599,7 @@ extern "C" int rtv_gemm_set_stream_workspace(rtv_stream_t stream, void* ptr, siz
 
 namespace rtv {
 
-int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream, bool allow_half) {
+int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream, bool allow_half, int extra_units) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return set_error(-1, "gemm: cannot query the device");
   float* slabs = nullptr;
@@ -600,9 +622,9 @@ int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipS
       }
     }
   }
-  *sp = SplitArgs{T, 1, nullptr, nullptr, 0, 0, 0};
+  *sp = SplitArgs{T, 1, nullptr, nullptr, 0, 0, 0, 0, 0, 0};
   *grid = T;
-  const int R = T % G;
+  const int R = (T + extra_units) % G <= T ? (T + extra_units) % G : 0;   // the tail units must be tiles
   // A tail that split-K would cut in TWO (R between G / 3 and G / 2 tiles): run it as 2 R half tiles (128 x 256, full K) instead -
   // the same parallelism without two prologues, a 256 KiB publish and a slab read per tile (tail cost 0.7-0.9 -> ~0.6 of a tile
   // time at K = 5120: o-projection 201 -> 193 us, QKV unchanged; at K = 13824 the K segments are long enough to win by 2 %:
@@ -643,7 +665,36 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
   if (int st = ensure_dynamic_lds((const void*)kern, g8::LDS_BYTES, &lds_attr, "gemm8")) return st;
   SplitArgs sp;
   int grid = 0;
-  if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8::BK, allow_split, &sp, &grid, stream, /*allow_half=*/true)) return st;
+  // Ragged last row of tiles (M = 4680: 72 real rows of 256) as 128 x 512 STRIPS in front of the tile grid (r04): two horizontally
+  // adjacent half tiles through the 128-row body, one after the other, so the row costs tiles_n / 2 workgroup slots instead of
+  // tiles_n.  Used only where that removes the tail round altogether: ffn-in at M = 4680 is 19 x 54 = 1026 tiles = 4 rounds + 2
+  // tiles (round 3 ran the two first, as 16 split-K units: 536 us); as 972 tiles + 27 strips it is 1004 slots = four rounds, no
+  // split, no slabs: 488-510 us (hipBLASLt 503-514).  Where a tail round remains anyway (QKV, o, ffn-out) the strips cost 3-8 %:
+  // the old tail already runs a ragged tile as ONE half tile, and a 1.1-tile-time unit delays its CU's share of the tail.  Every
+  // form that lets a workgroup finish a cheaper unit in the MIDDLE of a round (ragged tiles as single half tiles inside the grid)
+  // lost 7-18 % on every shape: that workgroup runs ahead of the tiles it shares panels with (profiles/r04_gemm_ragged_row.log).
+  // The strips keep the plain kernel's K order per output element (bit-identical with tile config 4).
+  const int G = device_num_cus();
+  const int last_rows = p.M - (p.tiles_m - 1) * g8::BM;
+  const int T0 = p.tiles_m * p.tiles_n;
+  int pair_units = 0, pair_pad = 0;
+  if (allow_split && g_gemm8_ragged_strips.load(std::memory_order_relaxed) && p.tiles_m >= 2 && last_rows <= 128 && G > 0 && T0 > G) {
+    const int pu = (p.tiles_n + 1) / 2, pp = (pu + 7) & ~7;   // ids [0, pp), pp % 8 == 0: a block's XCD is its id % 8 and the
+    const int RA = T0 % G;                                    // tile section must start at a multiple of 8 (xcd_remap)
+    if (RA > 0 && RA <= p.tiles_n - pp) {                     // the strips' saving swallows the whole tail round
+      pair_units = pu;
+      pair_pad = pp;
+      p.tiles_m -= 1;
+    }
+  }
+  if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8::BK, allow_split, &sp, &grid, stream, /*allow_half=*/true, pair_pad))
+    return st;
+  if (pair_units) {
+    sp.pair_units = pair_units;
+    sp.pair_pad = pair_pad;
+    sp.pair_m0 = p.tiles_m * g8::BM;
+    grid += pair_pad;
+  }
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8::LDS_BYTES, stream, p, sp);
   return check_launch("gemm8");

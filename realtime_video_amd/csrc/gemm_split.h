@@ -24,11 +24,20 @@ struct SplitArgs {
   int split_first;  // 1: the split units get the lowest block ids (dispatched first): chosen when there are few of them
   int half_tail;    // 1 (gemm8 only): the R tail tiles run as 2 R units of 128 x 256 (rows 0-127 / 128-255 of the tile, full K, the
                     // 128-row ping-pong body) instead of K segments: no slabs, no reduction; S is 1 then
+  int pair_units;   // > 0 (gemm8 only, r04): the ragged LAST row of tiles (<= 128 real rows) is not part of the tile grid (tiles_m is
+                    // one less); it runs as `pair_units` strips of 128 x 512 - two horizontally adjacent half tiles through the 128-row
+                    // body, one after the other - in block ids [0, pair_units); ids up to pair_pad (a multiple of 8) are padding
+                    // and every later id is shifted by pair_pad
+  int pair_pad;
+  int pair_m0;      // first row of the ragged row of tiles
 };
 
 // host: decide the split for T tiles of nk K-tiles each (defined in gemm8.hip, which owns the workspace pointers).
 // Fills *sp / *grid.  Returns 0 or an error status.
-int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream, bool allow_half = false);
+// `extra_units`: workgroup slots of about one tile time that run beside the T tiles (gemm8's ragged-row strips incl. their padding
+// ids): they count for the round arithmetic (R = (T + extra_units) % G) but are not tiles.
+int plan_split_k(int T, int nk, bool allow_split, SplitArgs* sp, int* grid, hipStream_t stream, bool allow_half = false,
+                 int extra_units = 0);
 
 // device: block id -> (tile, K segment).  Returns true when this workgroup is a split unit.
 // The units of the tail round are laid out for L2 locality like the full tiles are: every XCD gets a contiguous chunk of the

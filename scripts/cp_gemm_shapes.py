@@ -40,7 +40,8 @@ for m in [int(x) for x in os.environ.get("CP_M", "4680,2340,1170,585").split(","
         def variant(c):
             def run():
                 lib.rtv_gemm_set_skip_idle(0 if 1000 <= c < 2000 else 1)
-                lib.rtv_gemm_set_half_tail(0 if c >= 3000 else 1)
+                lib.rtv_gemm_set_half_tail(0 if 3000 <= c < 4000 else 1)
+                lib.rtv_gemm_set_ragged_strips(0 if c >= 4000 else 1)     # cfg 4000 + c: tile config c without the ragged-row strips
                 ops.gemm(a, w, bias=b, out=out, tile_cfg=c % 1000)
                 lib.rtv_gemm_set_half_tail(1)
             return run

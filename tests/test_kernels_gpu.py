@@ -593,6 +593,35 @@ def test_gemm_half_tile_tail_is_bit_identical_with_the_plain_launch(ops):
         lib.rtv_gemm_set_half_tail(1)
 
 
+def test_gemm_ragged_row_strips_are_bit_identical_with_the_plain_launch(ops):
+    """r04: where it removes the tail round, a ragged last row of 256-row tiles (M = 4680: 72 real rows) runs as 128 x 512 strips in
+    front of the tile grid - two half tiles through the 128-row body, full K (ffn-in: 19 x 54 = 1026 tiles = 4 rounds + 2 split-K
+    tiles -> 972 tiles + 27 strips = four rounds, no split).  Same bits as tile config 4 (no strips, no split-K) for both epilogue
+    families, an odd column-tile count (a strip of one half tile), 1 / 72 / 128 rows in the last tile; shapes where the rule does
+    not apply are unchanged; with the switch off the launch goes back to the round-3 form (split-K tail: fp32 re-association)."""
+    from realtime_video_amd import _lib
+    lib = _lib.load()
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    try:
+        # 256 CUs: strips apply to 1026 = 4 x 256 + 2 tiles (54 columns), 19 x 27 = 513 = 2 x 256 + 1 (27 columns, odd), not to 380
+        for M, N, K in ((4680, 13824, 1024), (4609, 13824, 256), (4736, 13824, 512), (4680, 6912, 1024), (4680, 5120, 1024),
+                        (4680, 15360, 512)):
+            a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+            r = _randn(M, N, seed=4)
+            gate = _randn(3, N, seed=5)
+            lib.rtv_gemm_set_ragged_strips(1)
+            got = (ops.gemm(a, w, bias=b, act=1, tile_cfg=5).clone(),
+                   ops.gemm(a, w, bias=b, gate=gate, gate_stride=N, rows_per_frame=(M + 2) // 3, residual=r, tile_cfg=5).clone())
+            ref = (ops.gemm(a, w, bias=b, act=1, tile_cfg=4),
+                   ops.gemm(a, w, bias=b, gate=gate, gate_stride=N, rows_per_frame=(M + 2) // 3, residual=r, tile_cfg=4))
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (M, N, K)
+            lib.rtv_gemm_set_ragged_strips(0)
+            off = ops.gemm(a, w, bias=b, act=1, tile_cfg=5)
+            assert rel_l2(off, ref[0]) <= 2e-3, (M, N, K)
+    finally:
+        lib.rtv_gemm_set_ragged_strips(1)
+
+
 def test_idle_wave_loops_change_nothing_but_the_time(ops):
     """Waves whose rows lie beyond M (gemm8_kernel) / beyond Lq (four-phase attention) run an idle loop - barriers and DMA duty
     only.  With the switch off they compute on clamped rows and the epilogue masks the result: the outputs must be bit-identical,
