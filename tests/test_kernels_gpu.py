@@ -593,6 +593,33 @@ def test_gemm_half_tile_tail_is_bit_identical_with_the_plain_launch(ops):
         lib.rtv_gemm_set_half_tail(1)
 
 
+def test_sampled_event_brackets_count_every_launch(ops):
+    """bench.py's roofline block brackets kernel launches with hipEvents (rtv_prof_*).  An event pair costs the launch stream a few
+    microseconds, so a class can be bracketed every n-th launch only (rtv_prof_set_stride): the sampled launches carry time and
+    work, ALL launches of the class are counted, and the class time is the sampled time scaled by work."""
+    a, w = _randn(512, 256, seed=1), _randn(384, 256, seed=2, scale=0.06)
+    try:
+        ops.prof_reset()
+        ops.prof_set_stride("gemm", 3)
+        ops.prof_enable(True, ["gemm"])
+        for _ in range(10):
+            ops.gemm(a, w)
+        ops.layernorm_modulate(_randn(64, 256, seed=3))            # another class: not enabled, not counted
+        torch.cuda.synchronize()
+        r = ops.prof_read("gemm")
+        assert r["launches"] == 4 and r["seen_launches"] == 10      # launches 0, 3, 6, 9
+        flops = 2.0 * 512 * 384 * 256
+        assert abs(r["work"] - 4 * flops) < 1 and abs(r["seen_work"] - 10 * flops) < 1
+        assert r["ms"] > 0 and abs(r["ms_class"] - r["ms"] * 2.5) <= 1e-9 * r["ms_class"]
+        assert ops.prof_read("layernorm")["seen_launches"] == 0
+        ops.prof_reset()
+        assert ops.prof_read("gemm")["seen_launches"] == 0
+    finally:
+        ops.prof_enable(False)
+        ops.prof_set_stride("gemm", 1)
+        ops.prof_reset()
+
+
 def test_gemm_ragged_row_strips_are_bit_identical_with_the_plain_launch(ops):
     """r04: where it removes the tail round, a ragged last row of 256-row tiles (M = 4680: 72 real rows) runs as 128 x 512 strips in
     front of the tile grid - two half tiles through the 128-row body, full K (ffn-in: 19 x 54 = 1026 tiles = 4 rounds + 2 split-K
