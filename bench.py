@@ -216,6 +216,9 @@ def main():
     from realtime_video_amd.vae_encoder import VAEEncoderWrapper
     from realtime_video_amd.wan_wrapper import WanDiffusionWrapper
 
+    if os.environ.get("RTV_ROPE_WAVE") is not None:      # A/B of the RoPE / cache kernel forms (include/rtv_hip_lab.h), diagnostic
+        from realtime_video_amd import _lib
+        _lib.load().rtv_rope_set_wave(int(os.environ["RTV_ROPE_WAVE"]))
     mc = MODELS[args.model]
     model = CausalWanModel(dim=mc["dim"], ffn_dim=mc["ffn_dim"], num_heads=mc["num_heads"], num_layers=mc["num_layers"],
                            text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)

@@ -38,6 +38,9 @@ int rtv_attn_set_skip_idle(int on);
 /* VAE 3x3x3 stride-1 convolutions on the halo-tile kernel (default 1) or on the implicit-GEMM gather kernel (0); same K order per
  * output pixel (bit-identical). */
 int rtv_conv_set_halo(int on);
+/* RMSNorm(q,k) + RoPE + cache-write kernel: -1 = by row count (default), 0 = one 256-thread workgroup per row, 1 = two waves per row.
+ * Same arithmetic per element; the fp32 sums of a row's squares are taken in another order. */
+int rtv_rope_set_wave(int mode);
 /* 1 when the library was built with -DRTV_LAB (experimental kernels present), else 0. */
 int rtv_lab_build(void);
 

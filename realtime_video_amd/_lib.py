@@ -47,6 +47,7 @@ SIGNATURES = {
     "rtv_gemm_set_skip_idle": [c_int],
     "rtv_gemm_set_ragged_strips": [c_int],
     "rtv_lab_build": [],
+    "rtv_rope_set_wave": [c_int],
     "rtv_gemm": [c_vp, c_int, c_vp, c_int, c_vp, c_int, c_int, c_int, c_int,
                  c_vp, c_int, c_vp, c_int, c_int, c_int, c_vp, c_int, c_int, c_int, c_vp],
     "rtv_layernorm_modulate": [c_vp, c_vp, c_int, c_int, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp],

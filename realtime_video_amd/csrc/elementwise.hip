@@ -8,6 +8,10 @@
 
 namespace rtv {
 
+// RoPE / cache kernel: -1 = by row count (wave form from ROPE_WAVE_MIN_ROWS rows on), 0 = workgroup per row, 1 = two waves per row
+static std::atomic<int> g_rope_wave{-1};
+constexpr int ROPE_WAVE_MIN_ROWS = 2048;
+
 constexpr int EW_THREADS = 256;
 constexpr int EW_MAXC = 4;  // rows of up to EW_THREADS * 8 * EW_MAXC = 8192 elements (16 chunks per lane of the row's wave)
 
@@ -260,16 +264,22 @@ __global__ __launch_bounds__(EW_THREADS) __attribute__((amdgpu_waves_per_eu(CPL 
     }
   }
   if (!norm) return;
-  float sx = 0.f;
+  // The sum of squares in the CANONICAL order both forms of this kernel share (so that the form - chosen by the launch's row count -
+  // never shows in the bits: a token shard of 585 rows and the unsharded 4680 rows give the same K / V): lane column l keeps four
+  // accumulators, acc[w] += squares of chunk l + 64 (w + 4 i) for i = 0, 1, ... (elements in order, fused multiply-add) - exactly
+  // what thread (wave w, lane l) of the workgroup-per-row form accumulates -, then ((acc0 + acc1) + acc2) + acc3, then the 64-lane
+  // butterfly.
+  float acc4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < CPL; ++i) {
     if (lane + i * 64 < nchunks) {
       float t[8];
       unpack_bf16x8(raw[i], t);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sx += t[j] * t[j];
+      for (int j = 0; j < 8; ++j) acc4[i & 3] = __builtin_fmaf(t[j], t[j], acc4[i & 3]);
     }
   }
+  const float sx = ((acc4[0] + acc4[1]) + acc4[2]) + acc4[3];
   const float rx = rsqrtf(wave_sum(sx) / (float)d + a.eps);
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -289,6 +299,111 @@ __global__ __launch_bounds__(EW_THREADS) __attribute__((amdgpu_waves_per_eu(CPL 
       for (int j = 0; j < 8; ++j) x[j] = round_bf16(round_bf16(x[j] * rx) * w8[j]);
       rope8(x, LANE_CS ? cs : wc);
       *(u32x4*)(xo + g * x_group_stride + col) = pack_bf16x8(x);
+    }
+  }
+}
+
+// ---- the same pass with ONE 256-thread workgroup per row (the round 1-3 kernel): for launches of few rows - the token shards of
+// context parallelism (585 rows at 8 ranks) - where a launch lasts as long as its slowest row and four waves finish a row sooner
+// than one (r04: with the wave kernel on every launch the simulated 8-rank forward's row-kernel class went 96 -> 111 ms summed
+// over the shards, profiles/r04_row_kernels.txt).
+// Row sums in the canonical order of the wave form (see qk_norm_rope_cache_kernel): thread (wave w, lane l) holds acc_w(l); every
+// wave combines the four accumulators of its lane column in the order ((0 + 1) + 2) + 3 and runs the same 64-lane butterfly.
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red /* [512] */) {
+  const int l = threadIdx.x & 63;
+  red[threadIdx.x] = a;
+  red[256 + threadIdx.x] = b;
+  __syncthreads();
+  a = wave_sum(((red[l] + red[64 + l]) + red[128 + l]) + red[192 + l]);
+  b = wave_sum(((red[256 + l] + red[320 + l]) + red[384 + l]) + red[448 + l]);
+}
+
+__device__ __forceinline__ void rope8_cols(float* x, int col, int hd, int c0, int c1, int pos_f, int pos_h,
+                                      int pos_w, const float2* __restrict__ cs) {
+  const int half = hd >> 1;
+  const int pj0 = (col % hd) >> 1;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int pj = pj0 + t;
+    int pos = pj < c0 ? pos_f : (pj < c0 + c1 ? pos_h : pos_w);
+    float2 w = cs[pos * half + pj];
+    float a = x[2 * t], b = x[2 * t + 1];
+    x[2 * t] = a * w.x - b * w.y;
+    x[2 * t + 1] = a * w.y + b * w.x;
+  }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_block_kernel(RopeArgs a) {
+  __shared__ float red[512];
+  const int row = blockIdx.x;
+  const int d = a.d;
+  const int nchunks = d >> 3;
+  const bf16_t* qr = a.qkv + (size_t)row * 3 * d;
+  const bf16_t* kr = qr + d;
+  const bf16_t* vr = kr + d;
+  float q[EW_MAXC][8], k[EW_MAXC][8];
+  u32x4 vraw[EW_MAXC];
+  float sq = 0.f, sk = 0.f;
+  const bool do_q = a.parts & 1, do_kv = a.parts & 2;   // kernel-uniform
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      if (do_q) {
+        unpack_bf16x8(*(const u32x4*)(qr + c * 8), q[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sq = __builtin_fmaf(q[i][j], q[i][j], sq);
+      }
+      if (do_kv) {
+        unpack_bf16x8(*(const u32x4*)(kr + c * 8), k[i]);
+        vraw[i] = *(const u32x4*)(vr + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sk = __builtin_fmaf(k[i][j], k[i][j], sk);
+      }
+    }
+  }
+  block_sum2(sq, sk, red);
+  const float rq = rsqrtf(sq / (float)d + a.eps);
+  const float rk = rsqrtf(sk / (float)d + a.eps);
+
+  const int half = a.hd >> 1;
+  const int c1 = half / 3, c0 = half - 2 * c1;
+  const int per_frame = a.gh * a.gw;
+  const int grow = a.row_offset + row;  // global token index
+  const int f = grow / per_frame;
+  const int rem = grow - f * per_frame;
+  const int pos_h = rem / a.gw, pos_w = rem - pos_h * a.gw;
+  const int pos_f = a.start_frame + f;
+
+  const int gc = a.group_cols;
+  size_t kv_row = gc ? (size_t)row : (size_t)(a.cache_row0 + grow);
+  if (!gc && a.ring_size > 0 && (int)kv_row >= a.ring_lo)
+    kv_row = (size_t)(a.ring_lo + ((int)kv_row - a.ring_lo + a.ring_shift) % a.ring_size);
+  bf16_t* qo = a.q_out + (size_t)row * (gc ? gc : d);
+  bf16_t* ko = a.k_cache + kv_row * a.cache_row_stride;
+  bf16_t* vo = a.v_cache + kv_row * a.cache_row_stride;
+#pragma unroll
+  for (int i = 0; i < EW_MAXC; ++i) {
+    int c = threadIdx.x + i * EW_THREADS;
+    if (c < nchunks) {
+      float wq8[8], wk8[8];
+      unpack_bf16x8(*(const u32x4*)(a.wq + c * 8), wq8);
+      unpack_bf16x8(*(const u32x4*)(a.wk + c * 8), wk8);
+      const int g = gc ? (c * 8) / gc : 0;
+      const int col = c * 8 - g * gc;
+      if (do_q) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[i][j] = round_bf16(round_bf16(q[i][j] * rq) * wq8[j]);
+        rope8_cols(q[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
+        *(u32x4*)(qo + g * a.q_group_stride + col) = pack_bf16x8(q[i]);
+      }
+      if (do_kv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[i][j] = round_bf16(round_bf16(k[i][j] * rk) * wk8[j]);
+        rope8_cols(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
+        *(u32x4*)(ko + g * a.kv_group_stride + col) = pack_bf16x8(k[i]);
+        *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
+      }
     }
   }
 }
@@ -420,6 +535,11 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   a.ring_shift = ring_shift;
   a.parts = parts;
   ProfScope prof(PROF_ROPE, (hipStream_t)stream, (parts == 3 ? 6.0 : parts == 1 ? 2.0 : 4.0) * M * d * 2);
+  const int g_sel = g_rope_wave.load(std::memory_order_relaxed);
+  if (g_sel == 0 || (g_sel < 0 && M < ROPE_WAVE_MIN_ROWS)) {
+    hipLaunchKernelGGL(qk_norm_rope_cache_block_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);
+    return check_launch("qk_norm_rope_cache");
+  }
   const int waves = M * ((parts & 2) ? 2 : 1);   // two waves per row when k / v are processed (q and k normalise independently)
   const dim3 grid((waves + ROWS_PER_WG - 1) / ROWS_PER_WG);
 #define RTV_ROPE_CALL(CPL)                                                                                                  \
@@ -488,6 +608,11 @@ int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rt
 using namespace rtv;
 
 extern "C" {
+
+int rtv_rope_set_wave(int mode) {   // include/rtv_hip_lab.h
+  g_rope_wave.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);
+  return 0;
+}
 
 
 int rtv_layernorm_modulate(const void* x, void* out, int M, int d, float eps, const void* shift,

@@ -292,17 +292,25 @@ def _rope_cs(hd):
 
 
 @pytest.mark.parametrize("d,H,grid,start,row0", [(256, 2, (2, 6, 8), 3, 10), (1536, 12, (1, 30, 52), 5, 0),
-                                               (5120, 40, (1, 6, 8), 0, 7)])
-def test_qk_norm_rope_cache_matches_oracle(ops, d, H, grid, start, row0):
-    """RMSNorm(q,k) -> RoPE -> KV-cache write, causal_model.py:243-256, :143-171, :380-385."""
+                                               (5120, 40, (1, 6, 8), 0, 7), (8192, 64, (1, 3, 5), 2, 1)])
+@pytest.mark.parametrize("form", [0, 1])
+def test_qk_norm_rope_cache_matches_oracle(ops, d, H, grid, start, row0, form):
+    """RMSNorm(q,k) -> RoPE -> KV-cache write, causal_model.py:243-256, :143-171, :380-385 - both forms of the kernel (one 256-thread
+    workgroup per row: launches of few rows; two waves per row, r04: the full-size launches - chosen by row count in production,
+    forced here through include/rtv_hip_lab.h)."""
     from oracle import wan_oracle as wo
+    from realtime_video_amd import _lib
     M = grid[0] * grid[1] * grid[2]
     hd = d // H
     qkv = _randn(M, 3 * d, seed=1, scale=2.0)
     wq, wk = _randn(d, seed=2) * 0.1 + 1, _randn(d, seed=3) * 0.1 + 1
     kc = torch.zeros(M + 20, H, hd, dtype=torch.bfloat16, device=DEV)
     vc = torch.zeros_like(kc)
-    q = ops.qk_norm_rope_cache(qkv, kc, vc, row0, H, wq, wk, _rope_cs(hd), grid, start)
+    _lib.load().rtv_rope_set_wave(form)
+    try:
+        q = ops.qk_norm_rope_cache(qkv, kc, vc, row0, H, wq, wk, _rope_cs(hd), grid, start)
+    finally:
+        _lib.load().rtv_rope_set_wave(-1)
     c = qkv.cpu()
     freqs = wo.rope_table(hd)
     rq = wo.rope_apply(wo.rms_norm(c[:, :d], wq.cpu()).view(1, M, H, hd), grid, freqs, start)
@@ -313,6 +321,30 @@ def test_qk_norm_rope_cache_matches_oracle(ops, d, H, grid, start, row0):
     # rows outside the written window stay untouched
     assert float(kc[:row0].abs().sum()) == 0 and float(kc[row0 + M:].abs().sum()) == 0
     assert (q.cpu().view(1, M, H, hd) != rq).float().mean() <= 0.03
+
+
+def test_qk_norm_rope_cache_forms_are_bit_identical(ops):
+    """The RoPE / cache kernel has two forms chosen by the launch's row count (one workgroup per row for the few rows of a
+    context-parallel token shard, two waves per row for full-size launches).  They sum a row's squares in ONE canonical order, so the
+    form never shows in the bits - a sharded forward stays bit-identical with the unsharded one.  d = 256 ... 8192, ragged widths."""
+    from realtime_video_amd import _lib
+    lib = _lib.load()
+    try:
+        for d, H, grid in ((5120, 40, (1, 9, 13)), (1536, 12, (2, 5, 7)), (256, 2, (1, 4, 5)), (8192, 64, (1, 2, 3)), (1024, 8, (1, 6, 6))):
+            M, hd = grid[0] * grid[1] * grid[2], d // H
+            qkv = _randn(M, 3 * d, seed=d, scale=3.0)
+            wq, wk = _randn(d, seed=2) * 0.1 + 1, _randn(d, seed=3) * 0.1 + 1
+            outs = []
+            for form in (0, 1):
+                lib.rtv_rope_set_wave(form)
+                kc = torch.zeros(M + 4, H, hd, dtype=torch.bfloat16, device=DEV)
+                vc = torch.zeros_like(kc)
+                q = ops.qk_norm_rope_cache(qkv, kc, vc, 2, H, wq, wk, _rope_cs(hd), grid, 1)
+                outs.append((q.clone(), kc, vc))
+            for a, b in zip(*outs):
+                assert torch.equal(a, b), (d, H)
+    finally:
+        lib.rtv_rope_set_wave(-1)
 
 
 def test_modulation_table_and_sinusoid(ops):
@@ -830,10 +862,13 @@ def test_attention_two_segment_window_equals_concatenated_keys(ops, seg0, seg1):
     assert max_abs(out, _attn_ref(q, k, v)) <= 2e-2
 
 
-def test_qk_norm_rope_cache_ring_write(ops):
+@pytest.mark.parametrize("form", [0, 1])
+def test_qk_norm_rope_cache_ring_write(ops, form):
     """rtv_qk_norm_rope_cache_ring stores logical cache row r >= ring_lo at ring_lo + (r - ring_lo + shift) % size: the rows it
-    writes are the plain kernel's rows, permuted; everything else in the cache is untouched."""
+    writes are the plain kernel's rows, permuted; everything else in the cache is untouched.  Both forms of the kernel."""
+    from realtime_video_amd import _lib
     from realtime_video_amd.rope import rope_cos_sin_table
+    _lib.load().rtv_rope_set_wave(form)
     F_, gh, gw, H = 2, 6, 10, 2
     M, d = F_ * gh * gw, 256
     qkv = _randn(M, 3 * d, seed=1)
@@ -855,6 +890,7 @@ def test_qk_norm_rope_cache_ring_write(ops):
     assert torch.equal(ring[mask.to(DEV)], base[mask.to(DEV)])
     with pytest.raises(RuntimeError):
         ops.qk_norm_rope_cache(qkv, ring[:, 0], ring[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5, ring=(lo, 100, 3))
+    _lib.load().rtv_rope_set_wave(-1)
 
 
 # ----------------------------------------------------------------------------------------- scheduler step (one launch)
