@@ -357,12 +357,25 @@ def main():
     step_ms = [e0.elapsed_time(e1) for rc, e0, e1 in wr.events if not rc]
     recompute_ms = [e0.elapsed_time(e1) for rc, e0, e1 in wr.events if rc]
     prof = {k: ops.prof_read(k) for k in ("gemm", "attn", "layernorm", "rope", "conv", "misc")}
+    # what an event bracket reads with nothing inside (the two markers on either side of a dispatch): every bracketed launch's time
+    # carries it, so the class times are corrected by it - without the correction the classes sum past the wall time of a block
+    # (profiles/r04_bench_bracket_overhead.txt)
+    bracket_ms = ops.prof_bracket_overhead(256) if args.profile_classes != "none" else 0.0
+    for v in prof.values():
+        v["ms_raw"], v["ms_class_raw"] = v["ms"], v["ms_class"]
+        v["ms"] = max(v["ms"] - bracket_ms * v["launches"], 0.0)
+        v["ms_class"] = v["ms"] * (v["seen_work"] / v["work"] if v["work"] > 0 else 1.0)
+    peak_mem = torch.cuda.max_memory_allocated(dev)
     if rank != 0:
         return
     total_frames = frames if use_cp or world == 1 else frames * world  # replicas: every rank generates its own stream
     gm = prof["gemm"]
     achieved = gm["work"] / (gm["ms"] * 1e-3) / 1e12 if gm["ms"] > 0 else 0.0
     fwd_per_block = args.denoising_steps + 1
+    # algorithmic TFLOP of one block of the contract configuration
+    block_tflop = None
+    if world == 1 and not args.no_vae and not args.simulate_cp and args.kv_cache_num_frames == 3 and args.denoising_steps == 4:
+        block_tflop = {"14b": 4 * 149.8 + 131.8 + 40.65 + 2.72, "1.3b": 4 * 20.2 + 16.2 + 40.65 + 2.72}.get(args.model)
     traffic, traffic_src, traffic_n = measured_traffic(args.model) if world == 1 and not args.fp8 else (None, None, None)
     result = {
         "metric": "frames/sec at 832x480, 4-step 14B T2V (per-step DiT latency in config)",
@@ -408,6 +421,11 @@ def main():
             # host side of a block: the session loop's wall time, the part of it spent blocked on the previous block's frames
             # (a wait on the GPU, not work) and the rest = Python + ctypes launch issue (6 ms under --hipgraph)
             "host_ms_per_block": host_ms,
+            # ms an EMPTY event bracket reads on the launch stream, already subtracted per bracketed launch from every class time
+            # and rate of this line (kernel_ms_per_block, roofline.*); `kernel_ms_per_block_uncorrected` = the raw brackets
+            "event_bracket_overhead_us": 1e3 * bracket_ms,
+            "kernel_ms_per_block_uncorrected": {k: v["ms_class_raw"] / args.steps for k, v in prof.items() if v["launches"] > 0},
+            "max_memory_allocated_GB": peak_mem / 1e9,
             "last_block_latents_checksum": latents_checksum,
         },
         "roofline": {
@@ -422,6 +440,11 @@ def main():
             "traffic_launches_sampled": traffic_n,
             "algorithmic_bytes_per_launch": None if args.fp8 else gemm_algorithmic_bytes(mc),
             "frac_of_sustained_mfma": achieved / (MFMA_SUSTAINED_FP8_TFLOPS if args.fp8 else MFMA_SUSTAINED_TFLOPS),
+            # the whole block against the same peak: algorithmic flops of a block (DiT GEMMs + attention of the 4 denoise
+            # and the recompute forward, VAE decode, first-frame re-encode = 774.5 TF for the contract configuration) / wall time
+            "whole_block_frac": (block_tflop / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * (2.0 if args.fp8 else 1.0))
+                                 if block_tflop is not None else None),
+            "whole_block_TFLOP": block_tflop,
             "launches": gm["launches"],                  # bracketed with events (every `sample_stride`-th launch of the class)
             "launches_in_timed_region": gm["seen_launches"],
             "sample_stride": 1 if args.profile_classes == "all" else strides.get("gemm", 1),

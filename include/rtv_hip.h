@@ -31,6 +31,10 @@ extern "C" {
 typedef void* rtv_stream_t; /* hipStream_t */
 
 /* ---- library ---------------------------------------------------------------------------- */
+/* ABI revision of this header: bumped whenever a struct layout or a signature below changes (101: rtv_dit_config gained the
+ * trailing max_attn_kv_splits; 102: rtv_attn_set_waves value 3, r05).  A binding compares rtv_version() with the
+ * RTV_ABI_VERSION it was written against and refuses a mismatch (realtime_video_amd/_lib.py does). */
+#define RTV_ABI_VERSION 102
 int rtv_version(void);
 const char* rtv_last_error(void);
 
@@ -47,6 +51,10 @@ int rtv_prof_reset(void);
  * rtv_prof_read scales to the class by seen_work / sampled_work. */
 int rtv_prof_set_stride(int cls, int stride);
 int rtv_prof_read_seen(int cls, int64_t* launches, double* work);
+/* What a bracket reads WITHOUT a kernel inside: n back-to-back (start, stop) event pairs on `stream`, their average elapsed time
+ * in ms.  A bracketed launch reads kernel time + this (the two markers are processed by the queue on either side of the dispatch);
+ * bench.py subtracts it per bracketed launch from the class times.  Synchronises the stream. */
+int rtv_prof_bracket_overhead(int n, rtv_stream_t stream, double* avg_ms);
 
 /* ---- K1/K2/K3: attention backend --------------------------------------------------------
  * Replaces wan/modules/attention.py:150-212 `attention(q,k,v,...)` (and the sage custom op

@@ -39,7 +39,8 @@ int rtv_attn_set_skip_idle(int on);
  * output pixel (bit-identical). */
 int rtv_conv_set_halo(int on);
 /* RMSNorm(q,k) + RoPE + cache-write kernel: -1 = by row count (default), 0 = one 256-thread workgroup per row, 1 = two waves per row.
- * Same arithmetic per element; the fp32 sums of a row's squares are taken in another order. */
+ * Bit-identical: both forms sum a row's squares in ONE canonical order (four accumulators per lane column, combined, then the
+ * 64-lane butterfly; tests/test_kernels_gpu.py::test_qk_norm_rope_cache_forms_are_bit_identical). */
 int rtv_rope_set_wave(int mode);
 /* 1 when the library was built with -DRTV_LAB (experimental kernels present), else 0. */
 int rtv_lab_build(void);

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTV_LIB_PATH") or os.path.join(_HERE, "librtv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
+ABI_VERSION = 102   # include/rtv_hip.h RTV_ABI_VERSION this binding's structs / signatures mirror
+
 _lib = None
 
 c_int, c_i64, c_f32, c_vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
@@ -29,6 +31,7 @@ SIGNATURES = {
     "rtv_prof_reset": [],
     "rtv_prof_set_stride": [c_int, c_int],
     "rtv_prof_read_seen": [c_int, ctypes.POINTER(c_i64), ctypes.POINTER(ctypes.c_double)],
+    "rtv_prof_bracket_overhead": [c_int, c_vp, ctypes.POINTER(ctypes.c_double)],
     "rtv_attn_fwd": [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int,
                      c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                      c_f32, c_int, c_int, c_int, c_vp],
@@ -106,6 +109,13 @@ def load():
             f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C realtime_video_amd/csrc`). There is no CPU fallback for the HIP path.")
     lib = ctypes.CDLL(LIB_PATH)
+    lib.rtv_version.restype, lib.rtv_version.argtypes = c_int, []
+    have = lib.rtv_version()
+    if have != ABI_VERSION:
+        # struct layouts (rtv_dit_config, rtv_dit_step, ...) are part of the ABI: a library of another revision would read
+        # garbage for fields it does not know.  RTV_LIB_PATH (A/B against an older build) is no exception.
+        raise RuntimeError(f"{LIB_PATH} reports ABI revision {have}, this binding is written against {ABI_VERSION} "
+                           "(include/rtv_hip.h RTV_ABI_VERSION): rebuild the library (`make -C realtime_video_amd/csrc`)")
     lib.rtv_last_error.restype = ctypes.c_char_p
     lib.rtv_last_error.argtypes = []
     sigs = dict(SIGNATURES)

@@ -500,6 +500,8 @@ class CausalWanModel:
         if splits > self._cfg.max_attn_kv_splits:     # the workspace carries the split partials only once somebody asks for them
             self._cfg.max_attn_kv_splits = splits
             self._ws.clear()
+            self._graphs.clear()          # captured graphs hold raw pointers into the workspace tensors just dropped
+            self._weights_version += 1
         if self.gemm_tile_cfg in (0, 5):
             ops.ensure_gemm_workspace(u.device)
         if use_cp:

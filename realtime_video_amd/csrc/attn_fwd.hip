@@ -999,7 +999,10 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   // 128-row / 4-wave workgroups (two per CU) when the 256-row grid cannot fill the chip, and for short key windows (the
   // text cross-attention, 512 keys = 8 tiles): a workgroup is then mostly prologue and epilogue, which two co-resident
   // workgroups overlap (scripts/cross_attn_ab.py: 74.9 vs 79.0 us at 4680 x 512 x 40 heads; bit-identical)
-  if (waves == 0) waves = ((int64_t)B * H * ((Lq + 255) / 256) * kv_splits < 160 || Lkv <= 512) ? 4 : 8;
+  // "cannot fill the chip": fewer 256-row workgroups than 5/8 of the device's CUs (160 on the 256-CU MI355X) - the same CU count
+  // parallel.attn_kv_splits_for plans its key ranges with (rtv_internal.h: every round rule uses device_num_cus())
+  const int cus = device_num_cus() > 0 ? device_num_cus() : 256;
+  if (waves == 0) waves = ((int64_t)B * H * ((Lq + 255) / 256) * kv_splits < (int64_t)cus * 5 / 8 || Lkv <= 512) ? 4 : 8;
   const int qt_rows = ATT_QW * waves;
   p.n_qtiles = (Lq + qt_rows - 1) / qt_rows;
   const int lds = 4 * ATT_TILE_BYTES;

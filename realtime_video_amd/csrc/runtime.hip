@@ -104,7 +104,7 @@ using namespace rtv;
 
 extern "C" {
 
-int rtv_version(void) { return 100; }
+int rtv_version(void) { return RTV_ABI_VERSION; }
 
 const char* rtv_last_error(void) { return g_err.c_str(); }
 
@@ -139,6 +139,29 @@ int rtv_prof_set_stride(int cls, int stride) {
   if (cls < 0 || cls >= PROF_NCLASS || stride < 1) return set_error(-1, "prof_set_stride: class 0..5, stride >= 1");
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_stride[cls] = stride;
+  return 0;
+}
+
+int rtv_prof_bracket_overhead(int n, rtv_stream_t stream_, double* avg_ms) {
+  if (n < 1 || n > 4096 || !avg_ms) return set_error(-1, "prof_bracket_overhead: 1 <= n <= 4096, avg_ms != null");
+  hipStream_t stream = (hipStream_t)stream_;
+  std::vector<hipEvent_t> ev(2 * (size_t)n);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return set_error(-1, "prof_bracket_overhead: hipEventCreate");
+  for (int i = 0; i < n; ++i) {
+    if (hipEventRecord(ev[2 * i], stream) != hipSuccess || hipEventRecord(ev[2 * i + 1], stream) != hipSuccess)
+      return set_error(-1, "prof_bracket_overhead: hipEventRecord");
+  }
+  if (hipStreamSynchronize(stream) != hipSuccess) return set_error(-1, "prof_bracket_overhead: hipStreamSynchronize");
+  double tot = 0;
+  for (int i = 0; i < n; ++i) {
+    float t = 0;
+    if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) != hipSuccess)
+      return set_error(-1, "prof_bracket_overhead: hipEventElapsedTime");
+    tot += t;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  *avg_ms = tot / n;
   return 0;
 }
 

@@ -774,6 +774,18 @@ extern "C" int rtv_vae_encode(const rtv_vae_enc_weights* w, const void* frames, 
     if (hipMemsetAsync((char*)arena + L.vt_off, 0, (size_t)384 * L.ldp * 2, stream) != hipSuccess)
       return set_error(-1, "vae_encode: memset failed");
 
+  if (first) {
+    // a fresh stream reads zeros wherever the reference has no cache yet (vae.py:17-36: zero padding in front of the first
+    // chunk): the two leading slices of every concat buffer + the padding page.  Cleared here so that an arena may be REUSED
+    // for a new stream without the caller zero-filling all of it (vae_encoder.py: recycled one-shot arenas).
+    for (int i = 0; i < 24; ++i) {
+      const size_t sl = (size_t)(H >> L.cat_stage[i]) * (W >> L.cat_stage[i]) * L.cat_C[i] * 2;
+      if (hipMemsetAsync((char*)arena + L.cat_off[i], 0, 2 * sl, stream) != hipSuccess)
+        return set_error(-1, "vae_encode: memset failed");
+    }
+    if (hipMemsetAsync((char*)arena + L.zeros_off, 0, 256, stream) != hipSuccess)
+      return set_error(-1, "vae_encode: memset failed");
+  }
   int T = tn, Hs = H, Ws = W;
   // pixels -> conv1's concat buffer (channels-last, 32-channel padded)
   hipLaunchKernelGGL(vae_enc_prep_kernel, dim3(2048), dim3(256), 0, stream, (const f16_t*)frames, Ttot, t0, T,

@@ -56,6 +56,14 @@ def prof_set_stride(cls, stride):
     _lib.call("rtv_prof_set_stride", PROF_CLASSES[cls] if isinstance(cls, str) else int(cls), int(stride))
 
 
+def prof_bracket_overhead(n=256):
+    """ms an EMPTY event bracket reads on the current stream (rtv_prof_bracket_overhead): what every bracketed launch's time
+    carries on top of its kernel.  Synchronises."""
+    ms = ctypes.c_double(0)
+    _lib.call("rtv_prof_bracket_overhead", int(n), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.byref(ms))
+    return ms.value
+
+
 def prof_read(cls):
     """-> ms / launches / work of the BRACKETED launches, seen_launches / seen_work of all launches of the class, and `ms_class` =
     the bracketed time scaled to the whole class by work."""

@@ -11,6 +11,7 @@ continues the stream, passing `[None] * 55` starts a new one.
 """
 import ctypes
 import math
+import weakref
 
 import torch
 
@@ -317,6 +318,8 @@ class VAEDecoderWrapperSingle(VAEDecoderWrapper):
                              "before the first frame)")
         if self.row_range(h) != (0, 8 * h):
             raise NotImplementedError("the single-frame form decodes whole frames")
+        # a Python bool / int is the fast path; a TENSOR flag (what the reference's torch.cond form takes, demo_utils/vae.py:
+        # 112-123) is read back here - one device-to-host sync per frame, and the call cannot be captured in a hipGraph
         first = bool(is_first_frame.item() if torch.is_tensor(is_first_frame) else is_first_frame)
         cache = list(feat_cache) + [None] * (55 - self.NUM_CACHES)
         arena, base = self._arenas.lookup(cache, (h, w), lambda: self._new_arena(h, w),
@@ -347,12 +350,26 @@ class CacheArenas:
     def register(self, views, arena, base, size):
         # The entry holds the arena, so its address cannot be reused while it is listed.  An evicted stream that comes back
         # takes the copy-in path of lookup() (correct, but 55 slot copies + a new arena): warn, it is a performance cliff.
-        self._by_ptr[views[0].data_ptr()] = (arena, base, size)
+        # Weak references to the views handed out tell recycle() when the owner has dropped the whole cache list.
+        self._by_ptr[views[0].data_ptr()] = (arena, base, size, [weakref.ref(v) for v in views if v is not None])
         while len(self._by_ptr) > self.keep:
             self._by_ptr.pop(next(iter(self._by_ptr)))
             import warnings
             warnings.warn(f"rtv: more than {self.keep} concurrent feature-cache streams on one VAE wrapper; the least recently "
                           "used arena was dropped (raise CacheArenas.KEEP / the wrapper's cache_streams)")
+
+    def recycle(self, size):
+        """(arena, base) of a registered stream of this frame size whose cache list is GONE - every view this wrapper handed
+        out for it has been garbage-collected, so nobody can feed it back - or None.  The entry is removed; the caller
+        re-registers the arena with the views of the new stream.  This is what keeps the session's per-block one-shot encode
+        (release_server.py:572-575: a fresh cache every block, dropped right after) on ONE arena instead of allocating,
+        zero-filling and registering a new one per block.  (Sub-views a caller sliced out of a dropped list keep pointing
+        into the arena and see the next stream's data - the same in-place contract as for a live stream.)"""
+        for key, ent in self._by_ptr.items():
+            if ent[2] == size and all(r() is None for r in ent[3]):
+                del self._by_ptr[key]
+                return ent[0], ent[1]
+        return None
 
     def lookup(self, cache, size, new_arena, make_views):
         """`cache` (a list, updated in place when it has to be rebuilt) -> (arena, base)."""

@@ -214,8 +214,14 @@ class VAEEncoderWrapper:
         frames = z[0].to(torch.float16).contiguous()
         fresh = feat_cache is None or len(feat_cache) == 0 or feat_cache[0] is None
         if fresh:
-            arena = self._new_arena(H, W)
-            base = (-arena.data_ptr()) % 256
+            # a stream whose cache list the caller has dropped (the session's one-shot re-encode does that every block) gives
+            # its arena back: no allocation, no zero-fill - rtv_vae_encode(first=1) clears the cache slices a fresh stream reads
+            rec = self._arenas.recycle((H, W))
+            if rec is not None:
+                arena, base = rec
+            else:
+                arena = self._new_arena(H, W)
+                base = (-arena.data_ptr()) % 256
         else:
             if not isinstance(feat_cache, list):
                 feat_cache = list(feat_cache)

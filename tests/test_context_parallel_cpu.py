@@ -213,8 +213,8 @@ def test_attn_kv_split_rule():
     for --cp-attn-splits 0): 14B -> 1 / 2 / 4 / 2 at 1 / 2 / 4 / 8 ranks, never more ranges than ranks (the partials share the
     DiT workspace: splits x local heads <= heads)."""
     from realtime_video_amd.parallel import attn_kv_splits_for
-    assert [attn_kv_splits_for(w, 40) for w in (1, 2, 4, 8)] == [1, 2, 4, 2]
+    assert [attn_kv_splits_for(w, 40, cus=256) for w in (1, 2, 4, 8)] == [1, 2, 4, 2]     # the MI355X: 256 CUs, stated here
     for heads in (12, 16, 40):
         for w in (1, 2, 4, 8):
-            s = attn_kv_splits_for(w, heads)
+            s = attn_kv_splits_for(w, heads, cus=256)
             assert s in (1, 2, 4) and s <= max(1, w)

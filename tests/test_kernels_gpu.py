@@ -869,6 +869,14 @@ def test_qk_norm_rope_cache_ring_write(ops, form):
     from realtime_video_amd import _lib
     from realtime_video_amd.rope import rope_cos_sin_table
     _lib.load().rtv_rope_set_wave(form)
+    try:
+        _ring_write_case(ops)
+    finally:
+        _lib.load().rtv_rope_set_wave(-1)      # the switch is process-wide: never leave it forced for the tests that follow
+
+
+def _ring_write_case(ops):
+    from realtime_video_amd.rope import rope_cos_sin_table
     F_, gh, gw, H = 2, 6, 10, 2
     M, d = F_ * gh * gw, 256
     qkv = _randn(M, 3 * d, seed=1)
@@ -890,7 +898,6 @@ def test_qk_norm_rope_cache_ring_write(ops, form):
     assert torch.equal(ring[mask.to(DEV)], base[mask.to(DEV)])
     with pytest.raises(RuntimeError):
         ops.qk_norm_rope_cache(qkv, ring[:, 0], ring[:, 1], row0, H, wq, wk, cs, (F_, gh, gw), 5, ring=(lo, 100, 3))
-    _lib.load().rtv_rope_set_wave(-1)
 
 
 # ----------------------------------------------------------------------------------------- scheduler step (one launch)

@@ -525,6 +525,56 @@ def test_full_resolution_streaming_decode_matches_fp32_oracle():
             assert rel_l2(c[0, ::5, :, ::7, ::9].float(), c32[0, ::5, :, ::7, ::9]) <= 2e-2
 
 
+def test_full_resolution_streaming_encode_matches_fp32_oracle():
+    """The ENCODER at the benchmarked size: what bench.py's timed region and the session run every
+    block is a fresh single-frame encode of a 480 x 832 frame (the first-frame re-encode, release_server.py:572-575); webcam
+    mode streams 4-frame chunks on the returned cache (demo_utils/vae_block3.py:116-175).  Both against
+    `vae_oracle.encoder_wrapper_forward` evaluated in fp32 by torch on the device (its host evaluation is pinned to the
+    reference golden at the small size by test_vae_oracle_vs_golden.py).  Tolerances of the golden test above: latents
+    max-abs <= max(2 x the error of the same graph in eager fp16, 2e-2), hard cap 5e-2, rel-L2 <= 2e-2; cache contents
+    rel-L2 <= 2e-2.  The fresh call is then repeated after the streamed one has dirtied every buffer: a dropped stream's arena
+    is reused (no allocation, no registration: VERDICT r04 weak 8) and must give the same bits."""
+    from oracle import vae_oracle as vo
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    w = vo.make_vae_encoder_weights(seed=1)
+    g = torch.Generator().manual_seed(23)
+    # smooth frames + noise in [-1, 1]: low-frequency content like video, plus pixel noise that exercises every tap
+    base = F.interpolate(torch.rand(5, 3, 30, 52, generator=g) * 2 - 1, size=(480, 832), mode="bilinear", align_corners=False)
+    frames = (0.8 * base + 0.2 * (torch.rand(5, 3, 480, 832, generator=g) * 2 - 1)).permute(1, 0, 2, 3).unsqueeze(0)
+    enc = VAEEncoderWrapper(device=DEV)
+    enc.load_state_dict(w)
+    w32 = {k: v.float().to(DEV) for k, v in w.items()}
+    w16 = {k: v.half().to(DEV) for k, v in w.items()}
+    calls = [(frames[:, :, :1], False), (frames[:, :, 1:5], True)]
+    cache, cache32, cache16 = [None] * 55, [None] * 55, [None] * 55
+    first_mu = None
+    for i, (f, stream) in enumerate(calls):
+        f16 = f.half().to(DEV)
+        mu, cache = enc(f16, cache, stream=stream)
+        with torch.inference_mode():
+            ref, cache32 = vo.encoder_wrapper_forward(w32, f16.float(), cache32, stream=stream)
+            mu16, cache16 = vo.encoder_wrapper_forward(w16, f16, cache16, stream=stream)
+        assert mu.shape == ref.shape == (1, 16, 1, 60, 104) and mu.dtype == torch.float16
+        err, err16 = max_abs(mu.float(), ref), max_abs(mu16.float(), ref)
+        assert err <= max(2 * err16, 2e-2) and err <= 5e-2, (i, err, err16)
+        assert rel_l2(mu.float(), ref) <= 2e-2, (i, rel_l2(mu.float(), ref))
+        if i == 0:
+            first_mu = mu.clone()
+    assert sum(c is not None for c in cache) == 24
+    for c, c32 in zip(cache, cache32):
+        assert (c is None) == (c32 is None)
+        if c is not None:
+            assert tuple(c.shape) == tuple(c32.shape)
+            assert rel_l2(c[0, :, :, ::7, ::9].float(), c32[0, :, :, ::7, ::9]) <= 2e-2
+    # a fresh one-shot encode on the wrapper's recycled arena: same bits as the first call, nothing newly registered
+    del cache, c
+    n_arenas = len(enc._arenas._by_ptr)
+    for _ in range(3):
+        again, _ = enc(frames[:, :, :1].half().to(DEV), [None] * 55, stream=False)
+        assert torch.equal(again, first_mu)
+    assert len(enc._arenas._by_ptr) <= max(n_arenas, 1)
+
+
 def test_full_size_decode_row_sharded_equals_unsharded():
     """Streaming decode at the benchmarked size (latents 60 x 104 -> 480 x 832): first block (3 latent frames -> 9 pixel
     frames) and a streamed second block (12 frames); the 8 row stripes of the sharded decode (BASELINE config 4) are
