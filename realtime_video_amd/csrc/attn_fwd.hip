@@ -17,70 +17,9 @@
 //                        LDS transpose read (ds_read_b64_tr_b16).
 // Online softmax in the exp2 domain, f32 accumulation; per-row prefix limits implement the
 // block-causal mask of the KV-recompute pass without materialising a mask.
-#include "rtv_common.h"
-#include "rtv_internal.h"
+#include "attn_common.h"
 
 namespace rtv {
-
-struct AttnParams {
-  const uint16_t* q;
-  const uint16_t* k;
-  const uint16_t* v;
-  uint16_t* o;
-  int B, Lq, Lkv, H;
-  int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;  // element strides; head stride = 128
-  float scale_log2e;
-  int causal_block, q_offset;
-  int n_qtiles;
-  // two-segment key window (ring-indexed rolling KV cache, causal_model.py:363-379 without the shift copy): key v of the
-  // window is cache row v for v < n0 and row v + delta for v >= n0 (rows relative to k / v); n0 == Lkv: one segment.
-  int n0, delta;
-  int off0;   // four-phase kernel only: keys v < n0 are cache rows v + off0 (its k / v point at the lowest row of the window)
-  int skip_idle;  // four-phase kernel only: waves whose 32 query rows all lie beyond Lq run the idle loop (A/B switch)
-  // lockstep kernel only: key `dup_key` stands for dup_count identical keys (the zero-padded text rows of the cross-attention all
-  // have the same K and V): its score gets + dup_bias = log2(dup_count) / scale_log2e before the softmax.  -1: none.
-  int dup_key;
-  float dup_bias;
-  // KV split (flash-decoding style, for launches whose query grid cannot fill the chip: the head-parallel phase of a context-
-  // parallel rank has 5 heads x 19 query tiles): blockIdx.y = split s works on key tiles [ntiles*s/S, ntiles*(s+1)/S) of the
-  // workgroup's OWN tile count (block-causal: the tiles below its largest key limit) and leaves its UNNORMALISED O (fp32), its
-  // reference point m and its row sum l in part_o / part_ml; attn_combine_kernel merges.  A row whose keys in a range are all
-  // masked leaves (m, l, O) = (-1e30, 0, 0): weight 2^(-1e30 - m) = 0 in the merge.
-  int kv_splits;    // S (1: the kernel writes `o` itself)
-  float* part_o;    // [S][B*H][Lq][128]
-  float* part_ml;   // [S][B*H][Lq][2] = (m, l)
-};
-
-constexpr int ATT_D = 128;
-constexpr int ATT_QW = 32;            // query rows per wave
-constexpr int ATT_KT = 64;            // keys per tile
-constexpr int ATT_TILE_BYTES = ATT_KT * ATT_D * 2;  // 16 KiB
-
-template <int V>
-struct IntC {
-  static constexpr int value = V;
-};
-
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
-  if constexpr (F16)
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b),
-                                                  c, 0, 0, 0);
-  else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
-                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-template <bool F16>
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-  if constexpr (F16) return pack_f16x2(a, b);
-  else return pack_bf16x2(a, b);
-}
-
-__device__ __forceinline__ u32x2 lds_tr_read(const char* p) {
-  s16x4 t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((RTV_LDS s16x4*)p);
-  return __builtin_bit_cast(u32x2, t);
-}
 
 // Occupancy: ~220 unified registers -> 2 waves per SIMD (the second __launch_bounds__ argument), i.e. ONE 8-wave workgroup or
 // two 4-wave workgroups per CU.  A 6-wave build cannot help partial rounds: its workgroup would still occupy a CU for the
@@ -99,31 +38,6 @@ __device__ unsigned* g_attn_trace = nullptr;   // [512 blocks][2 waves][4 tiles]
 #else
 #define ATT_STAMP(i)
 #endif
-
-// KV split: this workgroup's share of the key tiles (wave-uniform).
-__device__ __forceinline__ void split_tile_range(const AttnParams& p, int ntiles, int* t_lo, int* t_hi) {
-  *t_lo = 0;
-  *t_hi = ntiles;
-  if (p.kv_splits > 1) {
-    const int s = blockIdx.y;
-    *t_lo = ntiles * s / p.kv_splits;
-    *t_hi = ntiles * (s + 1) / p.kv_splits;
-  }
-}
-
-// KV split epilogue: O^T unnormalised, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}; (m, l) once per row.
-__device__ __forceinline__ void store_partial(const AttnParams& p, int bh, int q_row, int g, const f32x16 (&oacc)[4], float m_run,
-                                              float l_tot) {
-  if (q_row >= p.Lq) return;
-  const size_t row = ((size_t)blockIdx.y * (p.B * p.H) + bh) * p.Lq + q_row;
-  float* po = p.part_o + row * ATT_D + 4 * g;
-#pragma unroll
-  for (int db = 0; db < 4; ++db)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *(f32x4*)(po + db * 32 + i * 8) = f32x4{oacc[db][4 * i], oacc[db][4 * i + 1], oacc[db][4 * i + 2], oacc[db][4 * i + 3]};
-  if (g == 0) *(f32x2*)(p.part_ml + row * 2) = f32x2{m_run, l_tot};
-}
 
 // Merge of the S partial results of a row: m = max m_s, w_s = 2^(m_s - m), O = sum w_s O_s / sum w_s l_s.
 // 16 threads per row (8 dims each), 16 rows per workgroup.
@@ -471,41 +385,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnParams p) {
 //     before its first read.
 // Registers: Q^T 32 + O^T 64 + S^T 32 + P^T 16 + fragments 64 = 208 of the 256 a wave has at two waves per SIMD.
 constexpr int ATT_NB = 3;   // ring slots per operand
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(IntC<I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-// Transpose read as inline asm: the builtin carries no pointer information, so behind a pending LDS DMA the compiler's
-// wait-count pass puts `s_waitcnt vmcnt(0)` in front of it (a whole DMA latency per tile).  The asm form is invisible to
-// that pass - the consumer side waits with lds_wait_frags() below.
-template <int OFF>
-__device__ __forceinline__ u32x2 lds_tr_read_at(uint32_t lds_addr) {
-  u32x2 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
-  return r;
-}
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read128_at(uint32_t lds_addr) {
-  u32x4 r;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF));
-  return r;
-}
-// s_waitcnt lgkmcnt(0) that the fragment registers depend on (so no consumer can be scheduled above it)
-__device__ __forceinline__ void lds_wait_frags(u32x4 (&f)[16]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
-  asm volatile("" : "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
-}
-// the value of lane ^ 32 without the LDS crossbar (ds_bpermute would queue behind the transpose reads in flight)
-__device__ __forceinline__ float xor32_max(float v) {
-  const unsigned u = __float_as_uint(v);
-  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lanes: [lo, lo], [hi, hi]}
-  return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-}
 
 #ifdef RTV_ATTN_TRACE
 #define ATT_STAMP8(i)                                                                   \
@@ -866,6 +745,10 @@ static std::atomic<int> g_attn_waves{0};     // 0 = by grid size (include/rtv_hi
 static std::atomic<bool> g_attn_lockstep{false};  // 256-row launches on the lockstep kernel only (A/B runs, tests)
 static std::atomic<bool> g_attn_force_pp{false};  // ... on the four-phase kernel whatever the window length
 static std::atomic<bool> g_attn_skip_idle{true};  // rtv_attn_set_skip_idle(0): A/B of the idle-wave loop
+static std::atomic<int> g_attn_w4{-1};            // >= 0: 256-row launches on the one-wave-per-SIMD kernel (attn_w4.hip), schedule variant
+namespace rtv {
+int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStream_t stream);   // attn_w4.hip
+}
 
 extern "C" int rtv_attn_set_skip_idle(int on) {
   g_attn_skip_idle = on != 0;
@@ -873,10 +756,12 @@ extern "C" int rtv_attn_set_skip_idle(int on) {
 }
 
 extern "C" int rtv_attn_set_waves(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82)
-    return set_error(-1, "attn_set_waves: 0 (auto), 4, 8, 81 (8 waves, lockstep schedule) or 82 (8 waves, four-phase schedule)");
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82 && !(waves >= 840 && waves <= 843))
+    return set_error(-1, "attn_set_waves: 0 (auto), 4, 8, 81 (256 rows, lockstep schedule), 82 (256 rows, four-phase schedule) or "
+                         "840..843 (256 rows, one wave per SIMD, schedule variant 0..3)");
   g_attn_lockstep = waves == 81;
   g_attn_force_pp = waves == 82;
+  g_attn_w4 = waves >= 840 ? waves - 840 : -1;
   g_attn_waves = waves > 8 ? 8 : waves;
   return 0;
 }
@@ -1035,6 +920,14 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
                            ((top0 > top1 ? top0 : top1) + ATT_KT) * rs_max * 2 < 0x7fffffffLL;
   // Short key windows (the 512-key cross-attention) stay on the lockstep kernel: the four-phase one stages two tiles before its
   // first MFMA and pays four barriers per tile (measured 93 vs 84 us at 4680 x 512 x 40; +1..4 % from 4680 keys on).
+  // One-wave-per-SIMD kernel (attn_w4.hip): bf16, one row range (a ring window's two ranges stay on the four-phase kernel), the
+  // window's byte extent inside a buffer descriptor.  Opt-in through rtv_attn_set_waves(840 + variant) until it is the default.
+  const int w4v = g_attn_w4;
+  if (waves == 8 && w4v >= 0 && !f16 && Lkv1 == 0 && dup_key < 0 && offsets_fit && Lkv >= 256) {
+    if (int st = launch_attn_w4(p, f16, w4v, g, (hipStream_t)stream)) return st;
+    if (kv_splits > 1) return combine();
+    return check_launch("attn_w4");
+  }
   if (waves == 8 && !g_attn_lockstep && offsets_fit && dup_key < 0 && (Lkv >= 1024 || g_attn_force_pp)) {
     p.k += (int64_t)base_shift * k_row_stride;
     p.v += (int64_t)base_shift * v_row_stride;

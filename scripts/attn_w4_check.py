@@ -1,0 +1,103 @@
+"""One-wave-per-SIMD attention kernel (csrc/attn_w4.hip) against the four-phase kernel: bit identity on a ladder of shapes (ragged
+windows, one-tile windows, block-causal prefix, strided cache views, KV split), then timing of every schedule variant on the DiT
+shapes (HIP events, 3 rounds of 10 launches, median).  usage (GPU box): python scripts/attn_w4_check.py [variants...]"""
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from realtime_video_amd import ops  # noqa: E402
+
+DEV = "cuda"
+VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3]
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * scale).to(torch.bfloat16)
+
+
+def ref_attn(q, k, v, lim=None):
+    qf, kf, vf = q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3)
+    s = qf @ kf.transpose(-1, -2) / 128 ** 0.5
+    if lim is not None:
+        mask = torch.arange(k.shape[1], device=DEV)[None, :] >= lim[:, None]
+        s = s.masked_fill(mask[None, None], float("-inf"))
+    return (torch.softmax(s, -1) @ vf).permute(0, 2, 1, 3)
+
+
+def check():
+    bad = 0
+    cases = [(1, 256, 256, 1, 0), (1, 600, 1024, 2, 0), (1, 333, 1000, 3, 96), (1, 256, 64, 1, 0), (1, 100, 70, 2, 0),
+             (1, 257, 129, 2, 0), (1, 1040, 1040, 2, 520), (1, 512, 191, 8, 0), (1, 1560, 3000, 8, 0), (2, 300, 333, 2, 0),
+             (1, 4680, 9360, 8, 0), (1, 4680, 4680, 8, 4680), (1, 9360, 9360, 8, 4680)]
+    for (B, Lq, Lkv, H, cb) in cases:
+        q = rnd(B, Lq, H, 128, seed=1)
+        k = (rnd(B, Lkv, H, 128, seed=2).float() * torch.linspace(0.3, 3.0, Lkv, device=DEV).view(1, Lkv, 1, 1)).to(torch.bfloat16)
+        v = rnd(B, Lkv, H, 128, seed=3)
+        q_off = Lkv - Lq if cb and Lkv > Lq else 0
+        ops.attn_set_waves(82)
+        a = ops.attn_fwd(q, k, v, causal_block=cb, q_offset=q_off).clone()
+        lim = None
+        if cb:
+            lim = torch.clamp(((torch.arange(Lq, device=DEV) + q_off) // cb + 1) * cb, max=Lkv)
+        err_pp = float((a.float() - ref_attn(q, k, v, lim)).abs().max()) if Lq * Lkv * H <= 4e8 else float("nan")
+        for var in VARIANTS:
+            ops.attn_set_waves(840 + var)
+            outs = [ops.attn_fwd(q, k, v, causal_block=cb, q_offset=q_off).clone() for _ in range(3)]
+            same = torch.equal(outs[0], a)
+            rep = torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+            diff = float((outs[0].float() - a.float()).abs().max())
+            nan = int(torch.isnan(outs[0].float()).sum())
+            print(f"w4 var {var}  B{B} Lq{Lq} Lkv{Lkv} H{H} cb{cb}: bit-identical with four-phase {same}  repeatable {rep}  "
+                  f"max|diff| {diff:.3e}  nan {nan}  (four-phase vs fp32 {err_pp:.2e})", flush=True)
+            bad += (not same) or (not rep)
+    # strided cache views (14B layer geometry: K/V adjacent in a [rows, 2, H, 128] arena)
+    H = 40
+    arena = rnd(1, 9360 + 700, 2, H, 128, seed=5)
+    kc, vc = arena[:, 300:300 + 9360, 0], arena[:, 300:300 + 9360, 1]
+    q = rnd(1, 4680, H, 128, seed=6)
+    ops.attn_set_waves(82)
+    a = ops.attn_fwd(q, kc, vc).clone()
+    for var in VARIANTS:
+        ops.attn_set_waves(840 + var)
+        o = ops.attn_fwd(q, kc, vc)
+        same = torch.equal(o, a)
+        print(f"w4 var {var}  strided cache views 4680 x 9360 x 40: bit-identical {same}  max|diff| {float((o.float() - a.float()).abs().max()):.3e}", flush=True)
+        bad += not same
+    ops.attn_set_waves(0)
+    return bad
+
+
+def bench():
+    for name, lq, lkv, h, cb in [("14B c=3 denoise", 4680, 9360, 40, 0), ("14B c=3 recompute (block-causal)", 4680, 4680, 40, 4680),
+                                 ("14B c=9 denoise", 4680, 18720, 40, 0), ("1.3B c=3", 4680, 9360, 12, 0)]:
+        q, k, v = rnd(1, lq, h, 128, seed=1), rnd(1, lkv, h, 128, seed=2), rnd(1, lkv, h, 128, seed=3)
+        o = torch.empty_like(q)
+        for mode in [82] + [840 + x for x in VARIANTS] + [82]:
+            ops.attn_set_waves(mode)
+            fn = lambda: ops.attn_fwd(q, k, v, out=o, causal_block=cb)
+            for _ in range(3):
+                fn()
+            ts = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 10)
+            ms = statistics.median(ts)
+            tag = "four-phase" if mode == 82 else f"w4 var {mode - 840}"
+            print(f"attn {name:34s} {tag:11s} {lq} x {lkv} x {h}: {ms * 1e3:8.0f} us  {4.0 * lq * lkv * h * 128 / ms / 1e9:7.0f} TF/s "
+                  f"(dense-equivalent)", flush=True)
+    ops.attn_set_waves(0)
+
+
+if __name__ == "__main__":
+    bad = check()
+    print(f"MISMATCHES: {bad}")
+    bench()

@@ -18,11 +18,11 @@ def main():
     print("# fp8 e4m3 linears (per-tensor dynamic activation scale, per-tensor weight scale), 14B width (d=5120, H=40, ffn=13824), one block of")
     print("# the session loop = four denoise forwards (M=4680, window growing to 4680 rows) + scheduler steps; latents [1,3,16,60,104]")
     print("# L  rel_l2(ours_fp8, oracle_fp8)  max_abs(ours_fp8, oracle_fp8)  rel_l2(ours_fp8, oracle_bf16)  rel_l2(oracle_fp8, oracle_bf16)  "
-          "rel_l2(K last layer: ours, oracle_fp8)")
+          "rel_l2(K last layer: ours, oracle_fp8)  rel_l2(K last layer: oracle_fp8, oracle_bf16)")
     for L in ladder:
         r = td.run_fp8_depth_case(L)
         print(f"{L:3d}  {r['rel_l2_vs_fp8_oracle']:.3e}  {r['max_abs_vs_fp8_oracle']:.3e}  {r['rel_l2_vs_bf16_oracle']:.3e}  "
-              f"{r['fp8_oracle_rel_l2_vs_bf16_oracle']:.3e}  {r['k_last_layer_rel_l2']:.3e}", flush=True)
+              f"{r['fp8_oracle_rel_l2_vs_bf16_oracle']:.3e}  {r['k_last_layer_rel_l2']:.3e}  {r['k_last_layer_fp8_oracle_vs_bf16_oracle']:.3e}", flush=True)
         torch.cuda.empty_cache()
 
 
