@@ -13,11 +13,15 @@
 extern "C" {
 #endif
 
-/* Workgroup shape of rtv_attn_fwd: 8 waves x 32 query rows (default) or 4 waves (128 rows) for launches whose 256-row grid
- * leaves most of the 256 CUs idle (< 160 workgroups); 0 = choose by grid size.  256-row launches over >= 1024 keys run the
- * four-phase kernel (K/V by LDS DMA, fragments read a phase ahead of their MFMAs, the two wave groups one phase apart),
- * shorter windows the lockstep one; 81 / 82 force the lockstep / four-phase schedule.  All variants compute every row with
- * the same arithmetic in the same order (bit-identical outputs). */
+/* Workgroup shape / kernel of rtv_attn_fwd.  0 = by grid size and window (default): 128-row workgroups (4 waves, lockstep
+ * kernel) for launches whose 256-row grid leaves most CUs idle (< 5/8 of the device's CUs) and for windows of <= 512 keys;
+ * otherwise 256-row workgroups - bf16 over one row range of >= 1024 keys on the one-wave-per-SIMD kernel (r05, attn_w4.hip:
+ * 4 waves x 64 rows, asm-owned accumulation registers), ring windows (two row ranges) / f16 on the four-phase kernel (8 waves x
+ * 32 rows, K / V by LDS DMA, the two wave groups one phase apart), shorter windows on the lockstep kernel.
+ * 4 / 8 = force the workgroup size; 81 / 82 = 256 rows on the lockstep / four-phase schedule; 840 + v = 256 rows on the
+ * one-wave-per-SIMD kernel, variant v where it applies (product build: 200 = default, 0; lab build: schedule + 10 x timing experiment +
+ * 100 x options, attn_w4.hip).  The lockstep, four-phase and one-wave-per-SIMD (variants without option bit 0) kernels compute
+ * every row with the same arithmetic in the same order: bit-identical outputs. */
 int rtv_attn_set_waves(int waves);
 
 /* gemm8 (256x256 ping-pong GEMM): tail round as 128x256 half tiles (default 1) or as K segments with an fp32 slab reduction (0).

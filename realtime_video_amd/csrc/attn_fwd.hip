@@ -745,7 +745,10 @@ static std::atomic<int> g_attn_waves{0};     // 0 = by grid size (include/rtv_hi
 static std::atomic<bool> g_attn_lockstep{false};  // 256-row launches on the lockstep kernel only (A/B runs, tests)
 static std::atomic<bool> g_attn_force_pp{false};  // ... on the four-phase kernel whatever the window length
 static std::atomic<bool> g_attn_skip_idle{true};  // rtv_attn_set_skip_idle(0): A/B of the idle-wave loop
-static std::atomic<int> g_attn_w4{-1};            // >= 0: 256-row launches on the one-wave-per-SIMD kernel (attn_w4.hip), schedule variant
+// 256-row launches on the one-wave-per-SIMD kernel (attn_w4.hip): >= 0 a forced kernel variant, -2 = where it applies, its
+// default variant (W4_DEFAULT), -1 = never (rtv_attn_set_waves(81 / 82) pin the older schedules)
+static std::atomic<int> g_attn_w4{-2};
+constexpr int W4_DEFAULT = 200;
 namespace rtv {
 int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStream_t stream);   // attn_w4.hip
 }
@@ -756,12 +759,12 @@ extern "C" int rtv_attn_set_skip_idle(int on) {
 }
 
 extern "C" int rtv_attn_set_waves(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82 && !(waves >= 840 && waves <= 843))
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82 && !(waves >= 840 && waves <= 1239))
     return set_error(-1, "attn_set_waves: 0 (auto), 4, 8, 81 (256 rows, lockstep schedule), 82 (256 rows, four-phase schedule) or "
-                         "840..843 (256 rows, one wave per SIMD, schedule variant 0..3)");
+                         "840 + v (256 rows, one wave per SIMD, kernel variant v: attn_w4.hip)");
   g_attn_lockstep = waves == 81;
   g_attn_force_pp = waves == 82;
-  g_attn_w4 = waves >= 840 ? waves - 840 : -1;
+  g_attn_w4 = waves >= 840 ? waves - 840 : (waves == 81 || waves == 82 ? -1 : -2);
   g_attn_waves = waves > 8 ? 8 : waves;
   return 0;
 }
@@ -920,10 +923,12 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
                            ((top0 > top1 ? top0 : top1) + ATT_KT) * rs_max * 2 < 0x7fffffffLL;
   // Short key windows (the 512-key cross-attention) stay on the lockstep kernel: the four-phase one stages two tiles before its
   // first MFMA and pays four barriers per tile (measured 93 vs 84 us at 4680 x 512 x 40; +1..4 % from 4680 keys on).
-  // One-wave-per-SIMD kernel (attn_w4.hip): bf16, one row range (a ring window's two ranges stay on the four-phase kernel), the
-  // window's byte extent inside a buffer descriptor.  Opt-in through rtv_attn_set_waves(840 + variant) until it is the default.
-  const int w4v = g_attn_w4;
-  if (waves == 8 && w4v >= 0 && !f16 && Lkv1 == 0 && dup_key < 0 && offsets_fit && Lkv >= 256) {
+  // One-wave-per-SIMD kernel (attn_w4.hip; r05): the default for 256-row bf16 launches over one row range of >= 1024 keys (a ring
+  // window's two ranges, f16 and counted keys stay on the four-phase / lockstep kernels): 748 vs 790-815 us on 4680 x 9360 x 40,
+  // 390 vs 410 on the block-causal recompute shape, bit-identical (profiles/r05_attn_w4_*.log).
+  int w4v = g_attn_w4;
+  if (w4v == -2) w4v = Lkv >= 1024 ? W4_DEFAULT : -1;
+  if (waves == 8 && w4v >= 0 && !f16 && Lkv1 == 0 && dup_key < 0 && offsets_fit) {
     if (int st = launch_attn_w4(p, f16, w4v, g, (hipStream_t)stream)) return st;
     if (kv_splits > 1) return combine();
     return check_launch("attn_w4");

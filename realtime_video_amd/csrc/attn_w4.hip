@@ -42,35 +42,45 @@ constexpr int QW = 64;                                     // query rows per wav
 
 // ------------------------------------------------------------------------------------------------------------------------
 // The softmax of ONE tile as a stream of single VALU instructions, in issue order.  Per wave two query blocks qb; a block's 32
-// scores per lane are v[0..31] = S[qb][0][0..15], S[qb][1][0..15]; pair u = 2 w + qb, w = 0..15 = elements 2t, 2t+1 of 32-key
-// block kbk (w = 8 kbk + t) -> half a P^T register.
-//   MAX (qb, k) k = 0..15   mx = max3(mx, v, v')                                   the two blocks alternate: no instruction
-//   XCH0 / XCH1 (qb)        the other half of the row lives in lane ^ 32           depends on the one in front of it
-//   DEC (qb, k) k = 0..7    reference point, lazy-rescale decision, alpha, l *= alpha
-//   F0 / F1 (u)             x = s * c - m    for the two elements of the pair
-//   E0 / E1 (u)             e = exp2(x)
-//   A0 / A1 (u), CV (u)     row-sum partials += e, pack the pair
-//   SUM (qb, k) k = 0..1    l += partial sums
+// scores per lane are S[qb][h][0..15], h = 32-key block; pair u = 2 w + qb, w = 0..15 = elements 2t, 2t+1 of block kbk
+// (w = 8 kbk + t) -> half a P^T register.
+//   MAX (qb, h, k) k = 0..7  chain (qb, h): acc = max3(acc, v, v')      four chains alternate: no instruction depends on one
+//   CMB (qb)                 mx = max of the block's two chains          of the three in front of it
+//   XCH0 / XCH1 (qb)         the other half of the row lives in lane ^ 32
+//   DEC (qb, k) k = 0..5(6)  reference point, lazy-rescale decision, alpha (, l *= alpha)
+//   F0 / F1 (u)              x = s * c - m    for the two elements of the pair
+//   E0 / E1 (u)              e = exp2(x)
+//   A0 / A1 (u)              row-sum partials += e                       (not with RS)
+//   CV (u)                   pack the pair
+//   SUM (qb, k) k = 0..1     l += partial sums                           (not with RS)
 // F / E / {A, CV} are skewed by one pair each - F(k), E(k-1), A/CV(k-2) form a time step.
-enum OpKind { OP_MAX = 0, OP_XCH0, OP_XCH1, OP_DEC, OP_F, OP_E, OP_A, OP_CV, OP_SUM };
+// RS (row sums by the matrix pipe): l^T += 1 . P^T - one more MFMA per query block and 16-key step, all-ones A operand - instead
+// of the 64 additions + 4 of a tile: 8 MFMAs (256 matrix cycles) for 68 issue slots of a stream that is bound by its issue slots,
+// not by the matrix pipe (profiles/r05_attn_w4_ablation.log).  The sums are then taken over the bf16-ROUNDED probabilities, the
+// numbers O^T is accumulated from (the four-phase kernel sums the unrounded ones: the two kernels differ by rounding noise of
+// the normaliser, ~2^-9 / sqrt(keys) relative, instead of being bit-identical).
+enum OpKind { OP_MAX = 0, OP_CMB, OP_XCH0, OP_XCH1, OP_DEC, OP_F, OP_E, OP_A, OP_CV, OP_SUM };
 struct Op {
   int kind, qb, idx, sub, cost;
 };
 constexpr int N_PAIRS = 32;
-constexpr int N_OPS = 32 + 4 + 16 + 7 * N_PAIRS + 4;     // 280
+constexpr int MAX_OPS = 300;
 struct OpTable {
-  Op op[N_OPS];
+  Op op[MAX_OPS];
   int n;
 };
+template <bool RS>
 constexpr OpTable make_ops() {
   OpTable t{};
   int n = 0;
-  for (int k = 0; k < 16; ++k)
-    for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_MAX, qb, k, 0, 1};
+  for (int k = 0; k < 8; ++k)
+    for (int h = 0; h < 2; ++h)
+      for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_MAX, qb, k, h, 1};
+  for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_CMB, qb, 0, 0, 1};
   for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_XCH0, qb, 0, 0, 2};
   for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_XCH1, qb, 0, 0, 1};
-  for (int k = 0; k < 8; ++k)
-    for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_DEC, qb, k, 0, 1};
+  for (int k = 0; k < (RS ? 6 : 7); ++k)
+    for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_DEC, qb, k, 0, k == 3 ? 2 : 1};
   for (int k = 0; k < N_PAIRS + 2; ++k) {
     if (k < N_PAIRS) {
       t.op[n++] = Op{OP_F, k & 1, k, 0, 1};
@@ -81,68 +91,91 @@ constexpr OpTable make_ops() {
       t.op[n++] = Op{OP_E, (k - 1) & 1, k - 1, 1, 1};
     }
     if (k >= 2) {
-      t.op[n++] = Op{OP_A, (k - 2) & 1, k - 2, 0, 1};
-      t.op[n++] = Op{OP_A, (k - 2) & 1, k - 2, 1, 1};
+      if (!RS) {
+        t.op[n++] = Op{OP_A, (k - 2) & 1, k - 2, 0, 1};
+        t.op[n++] = Op{OP_A, (k - 2) & 1, k - 2, 1, 1};
+      }
       t.op[n++] = Op{OP_CV, (k - 2) & 1, k - 2, 0, 1};
     }
   }
-  for (int k = 0; k < 2; ++k)
-    for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_SUM, qb, k, 0, 1};
+  if (!RS)
+    for (int k = 0; k < 2; ++k)
+      for (int qb = 0; qb < 2; ++qb) t.op[n++] = Op{OP_SUM, qb, k, 0, 1};
   t.n = n;
   return t;
 }
-constexpr OpTable OPS = make_ops();
-static_assert(OPS.n == N_OPS, "op count");
 
-// Issue slots: 64 per tile's softmax = phase B of the previous tile's iteration (slots 0..31) then phase A (32..63).
-// What else a slot carries: B odd slots one K fragment read, B slots in dma_at one DMA piece, A odd slots the two transpose
-// reads of a V^T fragment.  The stream is cut so that every slot carries the same number of instructions (weights in quarter
-// instructions; a variant may price a DMA piece or an LDS read higher than a VALU instruction).
+// ---- the matrix instructions of phase B, in issue order.  Without RS: slot m = (step, db, qb) = (m >> 3, (m >> 1) & 3, m & 1);
+// with RS every 16-key step is followed by its two row-sum MFMAs: slot m = 10 step + j, j < 8 as before, j = 8, 9: l^T of qb j - 8.
+template <bool RS>
+struct PhaseB {
+  static constexpr int N = RS ? 40 : 32;
+  static constexpr int PER = RS ? 10 : 8;
+  static constexpr int step(int m) { return m / PER; }
+  static constexpr bool is_pv(int m) { return m % PER < 8; }
+  static constexpr int db(int m) { return (m % PER) >> 1; }
+  static constexpr int qb(int m) { return is_pv(m) ? (m % PER) & 1 : m % PER - 8; }
+  static constexpr int frag(int m) { return step(m) * 4 + db(m); }                              // V^T fragment of a PV slot
+  static constexpr int kread(int m) { return is_pv(m) && ((m % PER) & 1) ? frag(m) : -1; }    // K fragment read behind slot m
+  static constexpr int last_reader(int st) { return st * PER + PER - 1; }                      // last slot that reads P^T step st
+  static constexpr int first_slot_of_frag(int f) { return (f >> 2) * PER + 2 * (f & 3); }
+};
+
+// Issue slots of one tile's softmax: phase B of the previous tile's iteration (slots 0 .. NB-1) then phase A (NB .. NB+31).
+// What else a slot carries: the K fragment read behind the second PV MFMA of a V^T fragment, the DMA pieces (dma_at), in A the
+// two transpose reads of a V^T fragment behind odd slots.  The stream is cut so that every slot carries the same number of
+// instructions (weights in quarter instructions; a variant may price a DMA piece higher than a VALU instruction).
 struct SchedTable {
-  int begin[65];     // ops of slot s: [begin[s], begin[s + 1])
+  int begin[80];     // ops of slot s: [begin[s], begin[s + 1])
   bool ok;
 };
-template <int VAR>
+template <int VAR, bool RS>
 struct Sched {
-  // slot of B behind which DMA piece i (0-3 K, 4-7 V) is issued
-  static constexpr int dma_at(int i) { return VAR == 1 ? 16 + 2 * i : (VAR == 2 ? 1 + 4 * i : 2 + 2 * i); }
+  using PB = PhaseB<RS>;
+  static constexpr int NB = PB::N, NS = NB + 32;
+  static constexpr OpTable OPS = make_ops<RS>();
+  // slot of B behind which DMA piece i (0-3 K, 4-7 V) is issued: behind the FIRST MFMA of a fragment pair (the second carries
+  // the K fragment read); variant 1: late in the phase; variant 2: together with the K reads
+  static constexpr int dma_at(int i) {
+    const int f = VAR == 1 ? 8 + i : i + 1;                 // fragment pair whose first (2) / second slot carries the piece
+    return PB::first_slot_of_frag(f) + (VAR == 2 ? 1 : 0);
+  }
   static constexpr int dma_piece(int slot) {
     for (int i = 0; i < 8; ++i)
       if (dma_at(i) == slot) return i;
     return -1;
   }
-  static constexpr int W_DMA = VAR == 3 ? 12 : 4, W_K = 4, W_TR = 4;   // quarter instructions
+  static constexpr int W_DMA = VAR == 3 ? 12 : 6, W_K = 4, W_TR = 4;   // quarter instructions (a piece = s_add m0 + the load)
   static constexpr int others4(int s) {
-    if (s < 32) return ((s & 1) ? W_K : 0) + (dma_piece(s) >= 0 ? W_DMA : 0);
-    return (s & 1) ? 2 * W_TR : 0;
+    if (s < NB) return (PB::kread(s) >= 0 ? W_K : 0) + (dma_piece(s) >= 0 ? W_DMA : 0);
+    return ((s - NB) & 1) ? 2 * W_TR : 0;
   }
   static constexpr SchedTable make() {
     SchedTable t{};
     int tot = 0;
-    for (int i = 0; i < N_OPS; ++i) tot += 4 * OPS.op[i].cost;
-    for (int s = 0; s < 64; ++s) tot += others4(s);
-    // slot s ends where the cumulative cost reaches (s + 1) / 64 of the total
+    for (int i = 0; i < OPS.n; ++i) tot += 4 * OPS.op[i].cost;
+    for (int s = 0; s < NS; ++s) tot += others4(s);
+    // slot s ends where the cumulative cost reaches (s + 1) / NS of the total
     int g = 0, cum = 0, cum_other = 0;
-    for (int s = 0; s < 64; ++s) {
+    for (int s = 0; s < NS; ++s) {
       t.begin[s] = g;
       cum_other += others4(s);
-      const int target = (tot * (s + 1)) / 64 - cum_other;     // VALU quarter-instructions behind slots 0..s
-      while (g < N_OPS && cum + 2 * OPS.op[g].cost <= target) {  // an instruction belongs to the slot its midpoint falls in
+      const int target = (tot * (s + 1)) / NS - cum_other;       // VALU quarter-instructions behind slots 0..s
+      while (g < OPS.n && cum + 2 * OPS.op[g].cost <= target) {  // an instruction belongs to the slot its midpoint falls in
         cum += 4 * OPS.op[g].cost;
         ++g;
       }
     }
-    while (g < N_OPS) ++g;   // (rounding) the last slot takes what is left
-    t.begin[64] = g;
+    t.begin[NS] = OPS.n;   // (rounding) the last slot takes what is left
     t.ok = true;
-    // P^T hazard: the pack CV(u) writes P^T[qb][kbk][t >> 2] of the NEXT tile; PV of the current tile reads key step
-    // kbk * 2 + (t >> 2) in B slots 8 step .. 8 step + 7: the pack must sit behind the last of them
-    for (int s = 0; s < 64; ++s)
-      for (int gg = t.begin[s]; gg < (s == 63 ? N_OPS : t.begin[s + 1]); ++gg) {
+    // P^T hazard: the pack CV(u) writes P^T[qb][kbk][t >> 2] of the NEXT tile while phase B of the current one still reads
+    // that key step: the pack must sit behind the step's last reader
+    for (int s = 0; s < NS; ++s)
+      for (int gg = t.begin[s]; gg < t.begin[s + 1]; ++gg) {
         const Op G = OPS.op[gg];
         if (G.kind != OP_CV) continue;
-        const int w = G.idx >> 1, step = (w >> 3) * 2 + ((w & 7) >> 2);
-        if (s < 8 * step + 7) t.ok = false;
+        const int w = G.idx >> 1, st = (w >> 3) * 2 + ((w & 7) >> 2);
+        if (s < PB::last_reader(st)) t.ok = false;
       }
     return t;
   }
@@ -150,22 +183,31 @@ struct Sched {
   static constexpr int begin(int s) { return tab.begin[s]; }
 };
 
-// K fragment f (read behind B slot 2f+1) is consumed by the QK MFMAs of A slots 2f, 2f+1; V^T fragment f (two transpose reads
-// behind A slot 2f+1) by the PV MFMAs of B slots 2f, 2f+1.  LDS operations retire in order and lgkmcnt counts to 15: behind
-// the read of K fragment f there are 15 - f more K reads and 2 f transpose reads in front of its consumer (>= 15), behind the
-// reads of V^T fragment f 2 (15 - f) transpose reads and f K reads (>= 15): lgkmcnt(15) in front of every consumer is exact
-// for f = 0 and conservative by a few long-finished reads otherwise.
-constexpr int FRAG_WAIT = 15;
-static_assert(15 - 0 + 2 * 0 >= FRAG_WAIT && 2 * (15 - 15) + 15 >= FRAG_WAIT, "fragment wait count");
+// ---- fragment waits.  LDS operations of a wave retire in order.  Phase B issues the 16 K fragment reads of the next tile (one
+// behind the second PV MFMA of each V^T fragment), phase A the 32 transpose reads of the tile's V^T fragments (two behind every
+// odd slot).  Phase A consumes K fragment f in slots 2f, 2f+1:
+//   slot 0: lgkmcnt(14) - fragments 0, 1 have landed (14 younger K reads may be in flight);
+//   slot 4: lgkmcnt(15) - fragments 2, 3 (12 younger K reads + the 4 transpose reads of slots 1, 3 = 16 > 15: conservative);
+//   slot 8: lgkmcnt(8)  - every K read (only the 8 transpose reads of slots 1..7 are younger; the last K read is 9 slots old).
+// Phase B consumes V^T fragment f in its slots first_slot_of_frag(f), +1:
+//   slot 0: lgkmcnt(15) - of the 32 transpose reads the oldest 17 have landed: fragments 0..7 (key steps 0, 1);
+//   first slot of key step 2: lgkmcnt(8) - every transpose read (younger: the 8 K reads of steps 0, 1).
+constexpr int wait_a(int n) { return n == 0 ? 14 : (n == 4 ? 15 : (n == 8 ? 8 : -1)); }
+template <bool RS>
+constexpr int wait_b(int m) { return m == 0 ? 15 : (m == PhaseB<RS>::first_slot_of_frag(8) ? 8 : -1); }
 
 // ---- accumulation-register map (asm-owned)
 constexpr int A_O = 0;       // O^T [qb][db]: a[(qb*4 + db)*16 .. +15]
 constexpr int A_Q = 128;     // Q^T [qb][dc]: a[128 + (qb*8 + dc)*4 .. +3]
 constexpr int A_KV = 192;    // fragment f:   a[192 + 4 f .. +3]
-// Every asm statement that names accumulation registers clobbers ALL of them: no value of the compiler's can then live in an
-// accumulation register across any of these statements (left alone, its register allocator parks long-lived values - LDS
-// addresses, loop invariants - in "free" accumulation registers and reloads them with v_accvgpr_read: seen in the ISA, on top of
-// O^T).  scripts/micro/w4_audit.sh checks the outcome: no accumulation register in any instruction outside ASMSTART / ASMEND.
+// The compiler must never place a value of its own in an accumulation register: nothing in the asm statements tells it that
+// they are occupied (naming them as clobbers on every statement works - and costs an s_nop between any two statements, 3 per
+// MFMA).  What keeps it out is that it has no reason to enter: the architectural file holds everything it allocates with ~50
+// registers to spare (left to itself under pressure, its allocator parks long-lived values - LDS addresses, loop invariants - in
+// "free" accumulation registers and reloads them with v_accvgpr_read, on top of O^T: seen in the ISA of an earlier version).
+// scripts/micro/w4_audit.sh is the check, run by __graft_entry__.build() and by the CPU test suite: no accumulation register
+// in any instruction outside ASMSTART / ASMEND, no scratch, no spills.  The one clobber list below (kernel entry) makes the
+// kernel descriptor allocate all 256.
 #define RTV_W4_ACC \
   "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
   "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
@@ -201,6 +243,18 @@ __device__ __forceinline__ void mfma_pv(const u32x4& p_vgpr) {
   if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(p_vgpr), "n"(OF), "n"(OF + 15), "n"(VF), "n"(VF + 3));
   else asm volatile("v_mfma_f32_32x32x16_bf16 a[%c1:%c2], a[%c3:%c4], %0, a[%c1:%c2]" ::"v"(p_vgpr), "n"(OF), "n"(OF + 15), "n"(VF), "n"(VF + 3));
 }
+// l^T(VGPR) += ones (VGPR) . P^T (VGPR): every row of the 32 x 32 result is the row-sum vector of the 32 queries
+template <bool F16>
+__device__ __forceinline__ void mfma_rowsum(f32x16& l, const u32x4& ones, const u32x4& p_vgpr) {
+  if constexpr (F16) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(l) : "v"(ones), "v"(p_vgpr));
+  else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(l) : "v"(ones), "v"(p_vgpr));
+}
+// max without the canonicalising v_max hipcc puts in front of fmaxf on values it cannot prove quiet; volatile: ordered like a pin
+__device__ __forceinline__ float vmax(float a, float b) {
+  float r;
+  asm volatile("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <int DST, int OFF>
 __device__ __forceinline__ void lds_read128_a(uint32_t lds_addr) {
   asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%3" ::"v"(lds_addr), "n"(DST), "n"(DST + 3), "n"(OFF));
@@ -234,11 +288,27 @@ __device__ __forceinline__ void acc_settle() { asm volatile("s_nop 15\n\ts_nop 7
 
 }  // namespace w4
 
-template <bool F16, int VAR>
+#ifdef RTV_LAB   // cycle probe of the tile loop (lab build): per workgroup [shader cycles, 100 MHz ticks, tiles] of wave 0
+__device__ unsigned long long* g_w4_probe = nullptr;
+#endif
+
+// VARL = schedule variant (0..3) + 10 x LAB + 100 x OPT.
+// OPT bit 0: RS, row sums by the matrix pipe (see the op table); bit 1: DMA_IMM, one M0 write per operand and tile - a piece's
+// 1-KiB step is the instruction's immediate offset, which the hardware adds to the LDS AND the memory address (the per-lane
+// memory offsets carry the compensation).
+// LAB > 0 (lab build only, timing experiments, garbage results): 1 = no softmax instructions in the tile loop, 2 = exponentials
+// replaced by adds, 3 = no fragment reads, 4 = no DMA, 5 = no fragment waits, 6 = matrix instructions only (1 + 3 + 4 + 5).
+template <bool F16, int VARL>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
   using namespace w4;
-  using SC = Sched<VAR>;
-  static_assert(SC::tab.ok, "softmax schedule does not fit its slots / violates the P^T hazard");
+  constexpr int VAR = VARL % 10, LAB = (VARL / 10) % 10, OPT = VARL / 100;
+  constexpr bool RS = OPT & 1, DMA_IMM = OPT & 2;
+  constexpr bool NO_VALU = LAB == 1 || LAB == 6, NO_EXP = LAB == 2, NO_FRAG = LAB == 3 || LAB == 6, NO_DMA = LAB == 4 || LAB == 6,
+                 NO_WAIT = LAB == 5 || LAB == 6;
+  using SC = Sched<VAR, RS>;
+  using PB = PhaseB<RS>;
+  constexpr int NB = PB::N;
+  static_assert(SC::tab.ok, "softmax schedule violates the P^T hazard");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sK = smem;
   char* const sV = smem + V_BASE;
@@ -313,8 +383,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = st_row + 4 * i;
-    k_fast[i] = (uint32_t)(r * k_rs + (st_cp ^ (r & 15)) * 8) * 2u;
-    v_fast[i] = (uint32_t)(r * v_rs + (st_cp ^ ((r & 3) << 2)) * 8) * 2u;
+    k_fast[i] = (uint32_t)(r * k_rs + (st_cp ^ (r & 15)) * 8) * 2u - (DMA_IMM ? 1024u * i : 0u);   // r >= 4 i, row >= 256 bytes
+    v_fast[i] = (uint32_t)(r * v_rs + (st_cp ^ ((r & 3) << 2)) * 8) * 2u - (DMA_IMM ? 1024u * i : 0u);
   }
   auto tile_soff = [&](int t, int rs) __attribute__((always_inline)) { return (uint32_t)(min(t, t_last) * ATT_KT * rs) * 2u; };
   const uint32_t lds_wave = (uint32_t)(uintptr_t)(RTV_LDS char*)smem + (uint32_t)wave * 4096u;   // this wave's share of ring slot 0 of K
@@ -322,9 +392,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
   // iteration so that the 32 destination addresses of the unrolled loop are an s_add each, not 32 hoisted SGPRs
   auto piece = [&](auto vopc, auto slotc, auto ic, uint32_t lds_w, uint32_t soff) __attribute__((always_inline)) {
     constexpr int VOP = decltype(vopc)::value, SLOT = decltype(slotc)::value, I = decltype(ic)::value;
-    RTV_LDS void* dst = (RTV_LDS void*)(uintptr_t)(lds_w + (uint32_t)(VOP * V_BASE + SLOT * ATT_TILE_BYTES + I * 1024));
-    if constexpr (VOP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, dst, 16, v_fast[I], soff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, dst, 16, k_fast[I], soff, 0, 0);
+    constexpr int IMM = DMA_IMM ? I * 1024 : 0;
+    RTV_LDS void* dst = (RTV_LDS void*)(uintptr_t)(lds_w + (uint32_t)(VOP * V_BASE + SLOT * ATT_TILE_BYTES + I * 1024 - IMM));
+    if constexpr (VOP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcV, dst, 16, v_fast[I], soff, IMM, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcK, dst, 16, k_fast[I], soff, IMM, 0);
   };
   auto stage_tile = [&](auto vopc, auto slotc, int t) __attribute__((always_inline)) {   // all four pieces (prologue, idle waves)
     const uint32_t soff = tile_soff(t, decltype(vopc)::value ? v_rs : k_rs);
@@ -411,35 +482,45 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) P[qb][kb2][s] = u32x4{0u, 0u, 0u, 0u};
   float m_run[2] = {-1e30f, -1e30f};   // reference point of the exponentials (>= running max - RESCALE_SLACK), log2 domain
-  float l_run[2] = {0.f, 0.f};         // the lane's partial row sums
+  float l_run[2] = {0.f, 0.f};         // the lane's partial row sums                                   (not with RS)
+  f32x16 L[2];                         // RS: l^T accumulators - every element of a lane's 16 = its query's row sum
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) L[qb][r] = 0.f;
+  const uint32_t one2 = F16 ? 0x3c003c00u : 0x3f803f80u;
+  u32x4 ones = {one2, one2, one2, one2};
+  asm volatile("" : "+v"(ones));        // (a register quad, not four literals per MFMA)
   float alpha[2] = {1.f, 1.f};         // pending O^T rescale factor of the tile whose softmax has started
-  float mx[2] = {0.f, 0.f};
+  float mx[2] = {0.f, 0.f}, mxc[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, dec_t[2] = {0.f, 0.f}, dec_n[2] = {0.f, 0.f};
   float ps[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // row-sum partials of the tile in flight (even / odd elements, as the pp kernel)
   float px[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, pe[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // pipeline registers of the F / E / C stages
   unsigned long long need_any = 0;     // lanes whose row needs the rescale (either block): wave-uniform
   const float c = p.scale_log2e;
   constexpr float RESCALE_SLACK = 8.f;   // lazy rescaling, see the lockstep kernel
 
-  // one instruction of the softmax stream of the tile whose scores are in S[BUF]
-  float dec_t[2] = {0.f, 0.f};
-  unsigned long long dec_need[2] = {0ull, 0ull};   // ballots (SGPR pairs)
+  // one instruction of the softmax stream of the tile whose scores are in S[BUF].  Results are pinned behind their instruction
+  // (an empty asm that "modifies" them, or the instruction itself as volatile asm): hipcc otherwise sinks the whole softmax out of
+  // the matrix phases, sched_barrier notwithstanding.  A pinned value read by a VALU instruction less than two instructions
+  // later costs an s_nop (hipcc's pad behind inline asm): the four-chain / two-block interleaving keeps readers three away.
+#define RTV_PIN(x) asm volatile("" : "+v"(x))
   auto run_group = [&](auto bufc, auto gc) __attribute__((always_inline)) {
     constexpr int BUF = decltype(bufc)::value;
-    constexpr Op G = OPS.op[decltype(gc)::value];
+    constexpr Op G = SC::OPS.op[decltype(gc)::value];
     constexpr int qb = G.qb;
-    auto val = [&](auto ic) __attribute__((always_inline)) -> float {
-      constexpr int i = decltype(ic)::value;
-      return S[BUF][qb][i >> 4][i & 15];
-    };
-    // every result is pinned behind its instruction (an empty asm that "modifies" it): hipcc otherwise sinks the whole softmax out
-    // of the matrix phases, sched_barrier notwithstanding
-#define RTV_PIN(x) asm volatile("" : "+v"(x))
     if constexpr (G.kind == OP_MAX) {
-      constexpr int k = G.idx;
-      if constexpr (k == 0) mx[qb] = fmaxf(fmaxf(val(IntC<0>{}), val(IntC<1>{})), val(IntC<2>{}));
-      else if constexpr (k < 15) mx[qb] = fmaxf(fmaxf(mx[qb], val(IntC<2 * k + 1>{})), val(IntC<2 * k + 2>{}));
-      else mx[qb] = fmaxf(mx[qb], val(IntC<31>{}));
-      RTV_PIN(mx[qb]);
+      constexpr int k = G.idx, h = G.sub;
+      if constexpr (k == 0) {
+        mxc[qb][h] = fmaxf(fmaxf(S[BUF][qb][h][0], S[BUF][qb][h][1]), S[BUF][qb][h][2]);
+        RTV_PIN(mxc[qb][h]);
+      } else if constexpr (k < 7) {
+        mxc[qb][h] = fmaxf(fmaxf(mxc[qb][h], S[BUF][qb][h][2 * k + 1]), S[BUF][qb][h][2 * k + 2]);
+        RTV_PIN(mxc[qb][h]);
+      } else {
+        mxc[qb][h] = vmax(mxc[qb][h], S[BUF][qb][h][15]);
+      }
+    } else if constexpr (G.kind == OP_CMB) {
+      mx[qb] = vmax(mxc[qb][0], mxc[qb][1]);
     } else if constexpr (G.kind == OP_XCH0) {
       const unsigned u = __float_as_uint(mx[qb]);
       const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // {lanes: [lo, lo], [hi, hi]}
@@ -448,8 +529,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
       RTV_PIN(mx[qb]);
       RTV_PIN(dec_t[qb]);
     } else if constexpr (G.kind == OP_XCH1) {
-      mx[qb] = fmaxf(mx[qb], dec_t[qb]);
-      RTV_PIN(mx[qb]);
+      mx[qb] = vmax(mx[qb], dec_t[qb]);
     } else if constexpr (G.kind == OP_DEC) {
       // wave-uniform rare branch elsewhere, per-row decision here: rows that do not need it get alpha = exp2(0) = 1 exactly,
       // so a row's arithmetic never depends on which other rows share its wave (token-sharded == unsharded, bit for bit)
@@ -458,23 +538,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
         dec_t[qb] = mx[qb] * c;
         RTV_PIN(dec_t[qb]);
       } else if constexpr (k == 1) {
-        dec_t[qb] = fmaxf(m_run[qb], dec_t[qb]);                  // m_cand
-        RTV_PIN(dec_t[qb]);
+        dec_t[qb] = vmax(m_run[qb], dec_t[qb]);                  // m_cand
       } else if constexpr (k == 2) {
         mx[qb] = dec_t[qb] - m_run[qb];
         RTV_PIN(mx[qb]);
       } else if constexpr (k == 3) {
-        dec_need[qb] = __builtin_amdgcn_ballot_w64(mx[qb] > RESCALE_SLACK);
-        need_any |= dec_need[qb];
+        const bool need = mx[qb] > RESCALE_SLACK;
+        need_any |= __builtin_amdgcn_ballot_w64(need);
+        dec_n[qb] = need ? dec_t[qb] : m_run[qb];                 // the new reference point
+        RTV_PIN(dec_n[qb]);
       } else if constexpr (k == 4) {
-        dec_t[qb] = ((dec_need[qb] >> lane) & 1ull) ? dec_t[qb] : m_run[qb];        // the new reference point
-        RTV_PIN(dec_t[qb]);
-      } else if constexpr (k == 5) {
-        mx[qb] = m_run[qb] - dec_t[qb];
+        mx[qb] = m_run[qb] - dec_n[qb];
         RTV_PIN(mx[qb]);
-      } else if constexpr (k == 6) {
+      } else if constexpr (k == 5) {
         alpha[qb] = __builtin_amdgcn_exp2f(mx[qb]);
-        m_run[qb] = dec_t[qb];
+        m_run[qb] = dec_n[qb];
         RTV_PIN(alpha[qb]);
       } else {
         l_run[qb] *= alpha[qb];
@@ -486,7 +564,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
       RTV_PIN(px[st][G.sub]);
     } else if constexpr (G.kind == OP_E) {
       constexpr int st = G.idx & 1;
-      pe[st][G.sub] = __builtin_amdgcn_exp2f(px[st][G.sub]);
+      if constexpr (NO_EXP) pe[st][G.sub] = px[st][G.sub] + 1.0f;
+      else pe[st][G.sub] = __builtin_amdgcn_exp2f(px[st][G.sub]);
       RTV_PIN(pe[st][G.sub]);
     } else if constexpr (G.kind == OP_A) {
       constexpr int st = G.idx & 1;
@@ -508,12 +587,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
         ps[qb][1] = 0.f;
       }
     }
-#undef RTV_PIN
   };
-  // the groups of slot SLOT (0..31: phase B, 32..63: phase A) on the scores in S[BUF]
+#undef RTV_PIN
+  // the instructions of slot SLOT (0 .. NB-1: phase B, NB .. NB+31: phase A) on the scores in S[BUF]
   auto run_slot = [&](auto bufc, auto slotc) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slotc)::value;
-    static_for<SC::begin(SLOT), SC::begin(SLOT + 1)>([&](auto gc) __attribute__((always_inline)) { run_group(bufc, gc); });
+    if constexpr (!NO_VALU) static_for<SC::begin(SLOT), SC::begin(SLOT + 1)>([&](auto gc) __attribute__((always_inline)) { run_group(bufc, gc); });
   };
   // mask of the tile whose scores are in S[BUF] (global tile t): only on tiles that cross a limit of this wave.  Branch-free
   // integer form - s = min(s, kv < lim ? +inf : -inf) - so that the 64 decisions do not become 64 SGPR pairs
@@ -544,17 +623,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
     for (int db = 0; db < 4; ++db) va[db] = v_rd32[db];
     static_for<0, 32>([&](auto nc) __attribute__((always_inline)) {
       constexpr int n = decltype(nc)::value, dc = n >> 2, kbk = (n >> 1) & 1, qb = n & 1, f = n >> 1;
-      if constexpr (qb == 0) lds_wait<FRAG_WAIT>();
+      if constexpr (wait_a(n) >= 0 && !(NO_WAIT && FILL)) lds_wait<wait_a(n)>();
       mfma_qk<F16, A_KV + 4 * f, A_Q + (qb * 8 + dc) * 4, dc == 0>(S[NX][qb][kbk]);
       if constexpr (FILL) {
         __builtin_amdgcn_sched_barrier(0);
         // V^T fragment idx = (kbk*2 + s)*4 + db of tile i (ring slot C) into the registers K fragment idx has just left
-        if constexpr (n & 1) {
+        if constexpr ((n & 1) && !NO_FRAG) {
           constexpr int idx = n >> 1;
           constexpr int off = C * ATT_TILE_BYTES + ((idx >> 3) * 32 + ((idx >> 2) & 1) * 16) * 256;
           lds_tr_read_a<A_KV + 4 * idx, off>(va[idx & 3]);
         }
-        run_slot(IntC<CUR>{}, IntC<32 + n>{});
+        run_slot(IntC<CUR>{}, IntC<NB + n>{});
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -568,18 +647,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
     uint32_t ka[8];
 #pragma unroll
     for (int dc = 0; dc < 8; ++dc) ka[dc] = k_rd32[dc];
-    static_for<0, 32>([&](auto mc) __attribute__((always_inline)) {
-      constexpr int m = decltype(mc)::value, step = m >> 3, db = (m >> 1) & 3, qb = m & 1, f = m >> 1;
+    static_for<0, NB>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value, step = PB::step(m), qb = PB::qb(m);
       if constexpr (PV) {
-        if constexpr (qb == 0) lds_wait<FRAG_WAIT>();
-        mfma_pv<F16, A_O + (qb * 4 + db) * 16, A_KV + 4 * f>(P[qb][step >> 1][step & 1]);
+        if constexpr (wait_b<RS>(m) >= 0 && !NO_WAIT) lds_wait<wait_b<RS>(m)>();
+        if constexpr (PB::is_pv(m)) mfma_pv<F16, A_O + (qb * 4 + PB::db(m)) * 16, A_KV + 4 * PB::frag(m)>(P[qb][step >> 1][step & 1]);
+        else mfma_rowsum<F16>(L[qb], ones, P[qb][step >> 1][step & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (m & 1) {   // K fragment [dc][kbk] = n of tile i+2 (ring slot (C + 2) & 3) into the register V^T fragment f left
-        constexpr int n = m >> 1;
+      if constexpr (PB::kread(m) >= 0 && !(NO_FRAG && PV)) {   // K fragment [dc][kbk] = n of tile i+2 (ring slot (C + 2) & 3) into the
+        constexpr int n = PB::kread(m);                         // registers V^T fragment n has just left
         lds_read128_a<A_KV + 4 * n, ((C + 2) & 3) * ATT_TILE_BYTES + (n & 1) * 32 * 256>(ka[n >> 1]);
       }
-      if constexpr (SC::dma_piece(m) >= 0) {
+      if constexpr (SC::dma_piece(m) >= 0 && !(NO_DMA && PV)) {
         constexpr int i = SC::dma_piece(m);
         if constexpr (i < 4) piece(IntC<0>{}, IntC<C>{}, IntC<i>{}, lds_w, soff_k);                 // K(i+4) into the slot of K(i)
         else piece(IntC<1>{}, IntC<(C + 2) & 3>{}, IntC<i - 4>{}, lds_w, soff_v);                    // V(i+2)
@@ -596,13 +676,20 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
         constexpr int i = decltype(ic)::value;
         acc_scale<A_O + i>(alpha[i >> 6]);
       });
+      if constexpr (RS) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) L[qb][r] *= alpha[qb];
+      }
       acc_settle();
       need_any = 0;
     }
   };
   auto end_of_iteration = [&]() __attribute__((always_inline)) {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything but this iteration's 8 pieces has landed
+    if constexpr (NO_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // everything but this iteration's 8 pieces has landed
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -635,6 +722,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
   need_any = 0;   // O^T is still zero: nothing to rescale
   end_of_iteration();
 
+#ifdef RTV_LAB
+  const unsigned long long probe_c0 = __builtin_readcyclecounter(), probe_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- the tile loop, unrolled by the ring length
   for (int i = 0; i < n_it; i += 4) {
     iteration(IntC<0>{}, i);
@@ -645,6 +735,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
     if (i + 3 >= n_it) break;
     iteration(IntC<3>{}, i + 3);
   }
+#ifdef RTV_LAB
+  if (g_w4_probe != nullptr && wave == 0 && lane == 0 && blockIdx.x < 1024) {
+    g_w4_probe[blockIdx.x * 3 + 0] = __builtin_readcyclecounter() - probe_c0;
+    g_w4_probe[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memrealtime() - probe_r0;
+    g_w4_probe[blockIdx.x * 3 + 2] = (unsigned long long)n_it;
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pieces of the tiles past the end must not outlive the workgroup's LDS
 
   // ---------------- epilogue: O = O^T / l, lane owns row q and dims db*32 + 8*i + 4*g + {0..3}
@@ -656,7 +753,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
       constexpr int i = decltype(ic)::value;
       oq[i >> 4][i & 15] = acc_read<A_O + qb * 64 + i>();
     });
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+    float l_tot;
+    if constexpr (RS) l_tot = L[qb][0];   // the matrix pipe has summed all 64 keys of every tile, both lane halves
+    else l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
     if (p.kv_splits > 1) {
       store_partial(p, bh, q_row[qb], g, oq, m_run[qb], l_tot);
     } else {
@@ -677,11 +776,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
   });
 }
 
+#ifdef RTV_LAB
+}  // namespace rtv
+extern "C" int rtv_attn_w4_probe(unsigned long long* buf) {   // lab: [1024][3] u64, or null to switch the probe off
+  return hipMemcpyToSymbol(HIP_SYMBOL(rtv::g_w4_probe), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+namespace rtv {
+#endif
+
 // ---- launcher (called by attn_fwd_impl, attn_fwd.hip): p.n_qtiles = ceil(Lq / 256), grid and split set up by the caller
 int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStream_t stream) {
-  static LdsAttr attr[4];
+  static LdsAttr attr[400];
+  if (variant < 0 || variant >= 400) return set_error(-1, "attn_w4: variant out of range");
   if (f16) return set_error(-1, "attn_w4: bf16 only (f16 launches stay on the four-phase kernel)");
-  if (variant < 0 || variant > 3) return set_error(-1, "attn_w4: variant 0..3");
 #define RTV_W4_CASE(V)                                                                                        \
   case V: {                                                                                                   \
     const void* kp = (const void*)attn_fwd_w4_kernel<false, V>;                                               \
@@ -690,10 +797,28 @@ int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStr
     break;                                                                                                    \
   }
   switch (variant) {
-    RTV_W4_CASE(0)
+    RTV_W4_CASE(200)   // the product kernel: plain row sums (bit-identical with the four-phase kernel), one M0 write per operand
+    RTV_W4_CASE(0)     // the same with one M0 write per DMA piece
+#ifdef RTV_LAB
+    RTV_W4_CASE(100)
+    RTV_W4_CASE(300)
     RTV_W4_CASE(1)
     RTV_W4_CASE(2)
     RTV_W4_CASE(3)
+    RTV_W4_CASE(101)
+    RTV_W4_CASE(102)
+    RTV_W4_CASE(103)
+    RTV_W4_CASE(301)
+    RTV_W4_CASE(302)
+    RTV_W4_CASE(310)
+    RTV_W4_CASE(320)
+    RTV_W4_CASE(330)
+    RTV_W4_CASE(340)
+    RTV_W4_CASE(360)
+#endif
+    default:
+      return set_error(-1, "attn_w4: variant = schedule (0..3) + 10 x lab experiment + 100 x options; this build has 200 and 0 "
+                           "(lab build: more)");
   }
 #undef RTV_W4_CASE
   return 0;

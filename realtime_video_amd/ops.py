@@ -79,8 +79,8 @@ def prof_read(cls):
 
 # --------------------------------------------------------------------------------------- attention
 def attn_set_waves(waves=0):
-    """Workgroup shape of attn_fwd: 8 (256 query rows), 4 (128 rows) or 0 = by grid size; 81 / 82 = 256 rows on the lockstep /
-    four-phase schedule regardless of the window length (rtv_attn_set_waves)."""
+    """Workgroup shape / kernel of attn_fwd (rtv_attn_set_waves, include/rtv_hip_lab.h): 0 = by grid size and window; 4 / 8 = 128 /
+    256 query rows; 81 / 82 = 256 rows on the lockstep / four-phase schedule; 840 + v = the one-wave-per-SIMD kernel, variant v."""
     _lib.call("rtv_attn_set_waves", int(waves))
 
 

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from realtime_video_amd import ops  # noqa: E402
 
 DEV = "cuda"
-VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3]
+VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 100, 300]
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -53,7 +53,14 @@ def check():
             nan = int(torch.isnan(outs[0].float()).sum())
             print(f"w4 var {var}  B{B} Lq{Lq} Lkv{Lkv} H{H} cb{cb}: bit-identical with four-phase {same}  repeatable {rep}  "
                   f"max|diff| {diff:.3e}  nan {nan}  (four-phase vs fp32 {err_pp:.2e})", flush=True)
-            bad += (not same) or (not rep)
+            rs = (var // 100) & 1      # row sums by the matrix pipe: not bit-identical with the four-phase kernel by construction
+            ulp = float(((outs[0].view(torch.int16).int() - a.view(torch.int16).int()).abs()).max())
+            if rs:
+                err = float((outs[0].float() - ref_attn(q, k, v, lim)).abs().max()) if Lq * Lkv * H <= 4e8 else float("nan")
+                print(f"      RS: max bf16-ulp distance to four-phase {ulp:.0f}, vs fp32 {err:.2e}", flush=True)
+                bad += (not rep) or nan > 0 or ulp > 2 or (err == err and err > max(1.2 * err_pp, 2e-2))
+            else:
+                bad += (not same) or (not rep)
     # strided cache views (14B layer geometry: K/V adjacent in a [rows, 2, H, 128] arena)
     H = 40
     arena = rnd(1, 9360 + 700, 2, H, 128, seed=5)
@@ -65,8 +72,10 @@ def check():
         ops.attn_set_waves(840 + var)
         o = ops.attn_fwd(q, kc, vc)
         same = torch.equal(o, a)
-        print(f"w4 var {var}  strided cache views 4680 x 9360 x 40: bit-identical {same}  max|diff| {float((o.float() - a.float()).abs().max()):.3e}", flush=True)
-        bad += not same
+        ulp = float(((o.view(torch.int16).int() - a.view(torch.int16).int()).abs()).max())
+        print(f"w4 var {var}  strided cache views 4680 x 9360 x 40: bit-identical {same}  max|diff| {float((o.float() - a.float()).abs().max()):.3e}  "
+              f"max ulp {ulp:.0f}", flush=True)
+        bad += (ulp > 2) if (var // 100) & 1 else (not same)
     ops.attn_set_waves(0)
     return bad
 

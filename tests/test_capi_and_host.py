@@ -461,3 +461,22 @@ def test_vae_cache_arena_registry_finds_rebuilds_and_refuses():
         lists.append(make_views(torch.zeros(64 + 256, dtype=torch.uint8), 0, reg, (8, 12)))
     assert len(reg._by_ptr) == 3
     assert lists[0][0].data_ptr() in reg._by_ptr and lists[1][0].data_ptr() not in reg._by_ptr
+
+
+def test_attn_w4_audit_compiler_stays_out_of_the_accumulation_registers():
+    """csrc/attn_w4.hip names all 256 accumulation registers literally in inline asm (O^T, Q^T, K / V^T fragments): correct only
+    as long as hipcc never places a value of its own in one.  scripts/micro/w4_audit.sh compiles the product variant to ISA (no
+    GPU needed) and reports every accumulation register named outside ASMSTART / ASMEND, scratch use and spills: all must be 0,
+    and the tile loop must hold its 4 x 64 matrix instructions."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, W4_AUDIT_DIR=os.path.join(root, "realtime_video_amd", "csrc", "build", "w4_audit"))
+    out = subprocess.run([os.path.join(root, "scripts", "micro", "w4_audit.sh"), "200"], capture_output=True, text=True, env=env,
+                         timeout=600).stdout
+    assert re.search(r"instructions naming an accumulation register outside asm: 0\b", out), out
+    assert re.search(r"v_accvgpr outside asm: 0\b", out), out
+    assert re.search(r"\bscratch 0\b", out) and re.search(r"vgpr_spill_count: 0\b", out) and re.search(r"sgpr_spill_count: 0\b", out), out
+    assert re.search(r"private_segment_fixed_size: 0\b", out), out
+    assert len(re.findall(r"barrier  mfma=64 ", out)) == 4, out

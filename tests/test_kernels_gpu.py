@@ -527,7 +527,8 @@ def test_attention_duplicate_key_equals_repeated_keys(ops, Lq, n_real, total, H)
 
 
 @pytest.mark.parametrize("Lq,Lkv,H,splits,waves", [(4680, 2048, 5, 2, 0), (1100, 3000, 16, 2, 0), (585, 9360, 8, 3, 0), (300, 1000, 5, 4, 4),
-                                                   (257, 700, 3, 16, 8), (33, 100, 1, 5, 0), (600, 1500, 2, 2, 82)])
+                                                   (257, 700, 3, 16, 8), (33, 100, 1, 5, 0), (600, 1500, 2, 2, 82),
+                                                   (600, 1500, 2, 2, 840 + 200), (4680, 2048, 5, 2, 840 + 200), (300, 1300, 3, 4, 840 + 200)])
 def test_attention_kv_split_matches_unsplit(ops, Lq, Lkv, H, splits, waves):
     """rtv_attn_fwd_split (the self-attention launch of a context-parallel rank, xdit_context_parallel.py:179 in the reference):
     key window cut into `splits` ranges of 64-key tiles, one workgroup per (head, query tile, range), unnormalised fp32 partials
@@ -699,11 +700,12 @@ def test_idle_wave_loops_change_nothing_but_the_time(ops):
         for Lq, Lkv, H in ((4680, 2048, 4), (300, 1500, 2), (33, 1100, 3), (1000, 1024, 1)):
             q, k, v = _randn(1, Lq, H, 128, seed=4), _randn(1, Lkv, H, 128, seed=5), _randn(1, Lkv, H, 128, seed=6)
             outs = []
-            ops.attn_set_waves(82)                      # the four-phase kernel whatever the grid size
-            for on in (1, 0):
-                lib.rtv_attn_set_skip_idle(on)
-                outs.append(ops.attn_fwd(q, k, v).clone())
-            assert torch.equal(outs[0], outs[1]), (Lq, Lkv, H)
+            for kern in (82, W4):                       # the four-phase / the one-wave-per-SIMD kernel whatever the grid size
+                ops.attn_set_waves(kern)
+                for on in (1, 0):
+                    lib.rtv_attn_set_skip_idle(on)
+                    outs.append(ops.attn_fwd(q, k, v).clone())
+            assert all(torch.equal(outs[0], o) for o in outs[1:]), (Lq, Lkv, H)
             assert max_abs(outs[0], _attn_ref(q, k, v)) <= 2.5e-2
     finally:
         lib.rtv_gemm_set_skip_idle(1)
@@ -981,23 +983,31 @@ def test_scheduler_step_refuses_what_it_does_not_cover(ops):
 
 
 # ----------------------------------------------------------------------------------------- attention: four-phase kernel
+W4 = 840 + 200     # rtv_attn_set_waves: the one-wave-per-SIMD kernel (attn_w4.hip), product variant
+
+
 def _both_schedules(ops, fn):
+    """lockstep, four-phase, and - folded into the second result after an equality check - the one-wave-per-SIMD kernel (r05: where it
+    does not apply - f16, two-range windows - the launcher falls back to the four-phase kernel, which makes the check trivial)."""
     outs = []
     try:
-        for w in (81, 82):
+        for w in (81, 82, W4):
             ops.attn_set_waves(w)
             outs.append(fn())
     finally:
         ops.attn_set_waves(0)
-    return outs
+    assert torch.equal(outs[1], outs[2]), "one-wave-per-SIMD kernel != four-phase kernel"
+    return outs[:2]
 
 
 @pytest.mark.parametrize("B,Lq,Lkv,H,cb,dt", [
     (1, 600, 1024, 2, 0, torch.bfloat16), (1, 333, 1000, 3, 96, torch.bfloat16), (2, 300, 333, 2, 0, torch.float16),
     (1, 256, 64, 1, 0, torch.bfloat16), (1, 100, 70, 2, 0, torch.bfloat16), (1, 257, 129, 2, 0, torch.bfloat16),
-    (1, 1040, 1040, 2, 520, torch.bfloat16), (1, 512, 191, 8, 0, torch.bfloat16), (1, 1560, 3000, 8, 0, torch.bfloat16)])
+    (1, 1040, 1040, 2, 520, torch.bfloat16), (1, 512, 191, 8, 0, torch.bfloat16), (1, 1560, 3000, 8, 0, torch.bfloat16),
+    (1, 4680, 4680, 8, 4680, torch.bfloat16), (2, 700, 2100, 3, 0, torch.bfloat16), (1, 64, 4100, 1, 0, torch.bfloat16)])
 def test_attention_four_phase_kernel_equals_lockstep_and_reference(ops, B, Lq, Lkv, H, cb, dt):
-    """The four-phase kernel (LDS-DMA staging, fragments read a phase ahead) accumulates in the same order as the lockstep
+    """The four-phase kernel (LDS-DMA staging, fragments read a phase ahead) and the one-wave-per-SIMD kernel (r05: 4 waves x 64
+    rows, softmax pipelined across the matrix phases, asm-owned accumulation registers) accumulate in the same order as the lockstep
     one: outputs are bit-identical, on ragged windows, one-tile windows, the block-causal prefix and fp16 alike; both are
     within the stated tolerance of the fp32 reference.  Keys grow along the sequence so that rescales fire late."""
     q = _randn(B, Lq, H, 128, seed=1, dtype=dt)
