@@ -26,6 +26,9 @@ MODELS = {
     "1.3b": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30, name="Wan2.1-T2V-1.3B arch"),
     # test rig only (tests/test_context_parallel_gpu.py drives the launcher path with it): 8 heads -> one head per rank at 8 ranks
     "tiny": dict(dim=1024, ffn_dim=2048, num_heads=8, num_layers=2, name="TEST RIG (INVALID as a result): 2-layer d=1024 H=8"),
+    # --cp-host-probe: the 14B's 40 layers (= its count of host operations per forward) at a width whose kernels take microseconds,
+    # so that the launch queue never pushes back and the loop's wall time is the host's own cost
+    "hostrig": dict(dim=256, ffn_dim=512, num_heads=2, num_layers=40, name="HOST-COST RIG (INVALID as a result): 40-layer d=256 H=2"),
 }
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_TBPS = 8.0        # HBM3E, MI355X (MI355X_MICROARCH.md)
@@ -168,6 +171,11 @@ def main():
     ap.add_argument("--simulate-cp", type=int, default=0,
                     help="diagnostic (INVALID as a result): run all shards of an N-way context-parallel forward in lockstep "
                          "on this one GPU (no collectives, --no-vae implied); kernel_ms_per_block / N = one rank's compute")
+    ap.add_argument("--cp-host-probe", action="store_true",
+                    help="diagnostic (INVALID as a result): what the HOST side of the context-parallel forward costs per block - the "
+                         "Python loop of 4 C calls + 3 collectives per layer (causal_model.py) - measured without queue back-pressure: "
+                         "a ONE-rank process group (RCCL, collectives = self-exchanges through the same code path) on the 40-layer "
+                         "narrow rig; prints config.cp_host_ms_per_block (VERDICT r04 item 4)")
     ap.add_argument("--parallel", default="cp", choices=["cp", "replicas"],
                     help="N>1: cp = context-parallel single stream (strong scaling, RCCL all-gather per layer); "
                          "replicas = one independent stream per GPU (weak scaling, no collective)")
@@ -175,6 +183,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.cp_host_probe:
+        if args.gpus != 1:
+            raise SystemExit("--cp-host-probe is a one-rank measurement")
+        args.model, args.no_vae, args.no_cpu_baseline = "hostrig", True, True
+        args.profile_classes = "none"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
     shared_gpu = os.environ.get("RTV_BENCH_SHARED_GPU") == "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU of this node
@@ -207,6 +222,9 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif args.cp_host_probe:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from realtime_video_amd import ops
     from realtime_video_amd.causal_model import CausalWanModel
@@ -224,13 +242,11 @@ def main():
                            text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)
     model.gemm_tile_cfg = args.gemm_tile_cfg
     if args.hipgraph:
-        if world > 1 and args.parallel == "cp":
-            raise SystemExit("--hipgraph covers the single-GPU forward (the context-parallel path interleaves collectives)")
-        model.use_hip_graphs = True
+        model.use_hip_graphs = True      # (context parallel: the collectives are captured with the kernels, causal_model.py)
         args.profile_classes = "none"
     if args.fp8:
         model.enable_fp8()
-    use_cp = world > 1 and args.parallel == "cp"
+    use_cp = (world > 1 and args.parallel == "cp") or args.cp_host_probe
     cp_world = world if use_cp else max(1, args.simulate_cp)
     if args.cp_attn_splits <= 0:   # the count that fills the 256 CUs best for this rank count (parallel.attn_kv_splits_for)
         from realtime_video_amd.parallel import attn_kv_splits_for
@@ -240,6 +256,7 @@ def main():
         from realtime_video_amd.parallel import ContextParallel
         model.context_parallel = ContextParallel(exchange=args.cp_exchange, overlap=not args.no_cp_overlap,
                                                  attn_kv_splits=args.cp_attn_splits)
+        model.context_parallel.force_single_rank = bool(args.cp_host_probe)
     if args.simulate_cp > 1:
         from realtime_video_amd.parallel import SimulatedContextParallel
         model.context_parallel = SimulatedContextParallel(args.simulate_cp, args.cp_exchange, attn_kv_splits=args.cp_attn_splits)
@@ -388,7 +405,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if use_cp else "weak",
         "vs_baseline": ((total_frames / elapsed) / 11.0
-                        if args.model == "14b" and world == 1 and not args.no_vae and not args.fp8 and not args.simulate_cp else None),
+                        if args.model == "14b" and world == 1 and not args.no_vae and not args.fp8 and not args.simulate_cp
+                        and not args.cp_host_probe else None),
         "dtype": "fp8 e4m3 linears (per-tensor dynamic activations, fp32 accumulation), bf16 elsewhere" if args.fp8 else "bf16",
         "data": "synthetic (random-init weights of the named architecture, N(0,1) latents/noise, N(0,1) prompt embeddings)",
         "config": {
@@ -421,6 +439,10 @@ def main():
             # host side of a block: the session loop's wall time, the part of it spent blocked on the previous block's frames
             # (a wait on the GPU, not work) and the rest = Python + ctypes launch issue (6 ms under --hipgraph)
             "host_ms_per_block": host_ms,
+            # --cp-host-probe: the host side of ONE rank's context-parallel block (5 forwards x 40 layers x (4 C calls + 3
+            # collectives + event fences)), no queue back-pressure; to be held against the ~134 ms of GPU work a rank has at 8 ranks
+            "cp_host_ms_per_block": host_ms["launch_issue"] if args.cp_host_probe else None,
+            "cp_forwards_issued_from_python": getattr(model, "cp_forwards_issued", 0) if use_cp else None,   # (graph replays excluded)
             # ms an EMPTY event bracket reads on the launch stream, already subtracted per bracketed launch from every class time
             # and rate of this line (kernel_ms_per_block, roofline.*); `kernel_ms_per_block_uncorrected` = the raw brackets
             "event_bracket_overhead_us": 1e3 * bracket_ms,

@@ -455,7 +455,8 @@ class CausalWanModel:
             for c in crossattn_cache:
                 c["text_rows"] = n_real
         cp = self.context_parallel
-        use_cp = cp is not None and cp.world > 1
+        # (a one-rank group takes the plain forward unless the ContextParallel object insists: bench.py --cp-host-probe)
+        use_cp = cp is not None and (cp.world > 1 or getattr(cp, "force_single_rank", False))
         # `kv_cache_only` (a per-CALL argument, not in the reference signature: the session passes it for its KV-recompute pass,
         # whose output the reference discards as well, release_server.py:611-632): the forward stops behind the last layer's
         # K / V cache write; the returned tensor is zeros (not while the cross-attention caches are still to be filled: the last
@@ -546,78 +547,115 @@ class CausalWanModel:
             _lib.call("rtv_dit_forward", cfg_p, w_p, ctypes.byref(st), *wsa)
             commit()
         else:
-            # context parallel: local rows only, ONE K/V all-gather per layer (parallel.py).  `local_ranks` is
-            # [rank] in production; a single-process simulation of several ranks runs them in lockstep.
-            from .parallel import shard_rows
-            W, H = cp.world, self.num_heads
-            heads = cp.head_exchange(H)
-            keep = []
-            if heads:
-                # head exchange: every rank's step addresses the cache heads it owns (the whole cache when it was
-                # allocated with kv_cache_heads() heads, a head slice of a full-head cache otherwise)
-                hn = H // W
-                if kv_cache[0]["k"].shape[2] not in (hn, H):
-                    raise ValueError(f"KV cache must hold {hn} (this rank's) or {H} heads, not {kv_cache[0]['k'].shape[2]}")
-                parts = []
-                for i, r in enumerate(cp.local_ranks()):
-                    h0 = 0 if kv_cache[0]["k"].shape[2] == hn else r * hn
-                    ka, kp = ptr_array([c["k"][0, :, h0:h0 + hn] for c in kv_cache])
-                    va, vp = ptr_array([c["v"][0, :, h0:h0 + hn] for c in kv_cache])
-                    keep.append((ka, va))
-                    parts.append(make(shard_rows(M, W, r), i, kp, vp))
-                bufs = [(r, self._exchange_buffers(M, W, i, u.device)) for i, r in enumerate(cp.local_ranks())]
-            else:
-                parts = [make(shard_rows(M, W, r), i) for i, r in enumerate(cp.local_ranks())]
-            for st, wsa in parts:
-                _lib.call("rtv_dit_begin", cfg_p, w_p, ctypes.byref(st), *wsa)
-            # Per layer the projection runs in two pieces with the exchange of the first one in flight under the second
-            # (rtv_dit_layer_proj; the collective runs on the process group's communication stream):
-            #   rows  exchange: [LN | K,V] -> all-gather of the new K/V rows (async) -> [Q] -> wait -> attention ...
-            #   heads exchange: [LN | Q]   -> all-to-all(q) (async) -> [K,V] -> all-to-all(k|v) (async) -> wait both -> attention
-            null = c_vp(0)
-            for l in range(L):
-                last_kv_only = kv_only and l == L - 1      # only the K / V rows of the last layer are still needed
-                if not heads:
-                    for st, wsa in parts:
-                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, 0, null, null, *wsa)
-                    pend = cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
-                    if last_kv_only:
-                        pend.wait()
-                        break
-                    for st, wsa in parts:
-                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_Q, 0, null, null, *wsa)
-                    pend.wait()
-                    for st, wsa in parts:
-                        _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
-                    continue
-                if last_kv_only:
-                    for (st, wsa), (_, b) in zip(parts, bufs):
-                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, W, null,
-                                  c_vp(b["kv_send"].data_ptr()), *wsa)
-                    cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
-                    break
-                for (st, wsa), (_, b) in zip(parts, bufs):
-                    _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_Q, W,
-                              c_vp(b["q_send"].data_ptr()), null, *wsa)
-                pend_q = cp.exchange_q(bufs, async_op=True)
-                for (st, wsa), (_, b) in zip(parts, bufs):
-                    _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_KV, W, null,
-                              c_vp(b["kv_send"].data_ptr()), *wsa)
-                pend_kv = cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
-                pend_q.wait()
-                pend_kv.wait()
-                for (st, wsa), (_, b) in zip(parts, bufs):
-                    _lib.call("rtv_dit_layer_attn_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_all"].data_ptr()),
-                              c_vp(b["o_all"].data_ptr()), *wsa)
-                cp.exchange_o(bufs)
-                for (st, wsa), (_, b) in zip(parts, bufs):
-                    _lib.call("rtv_dit_layer_rest_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["o_recv"].data_ptr()), *wsa)
-            if not kv_only:
-                hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
+            # Context parallel.  With use_hip_graphs the whole forward - the per-layer C calls AND the collectives, which RCCL lets a
+            # stream capture record like kernels (the comm-stream fences become graph edges) - is captured once per launch geometry and
+            # replayed: the host side of a rank shrinks from ~1400 Python operations per block to five graph launches (r05; VERDICT r04
+            # item 4: bench.py --cp-host-probe measures both).  Same key and static-buffer rules as the single-GPU graph above.
+            graph_key = None
+            if self.use_hip_graphs and not need_cross:
+                graph_key = ("cp", cp.world, cp.head_exchange(self.num_heads), F, gh, gw, row0, lo, hi, start_frame, causal_block, kv_only,
+                             text_rows, int(self.gemm_tile_cfg), rs, self._weights_version, splits,
+                             kv_cache[0]["k"].data_ptr(), kv_cache[-1]["v"].data_ptr(), crossattn_cache[0]["k"].data_ptr())
+                ent = self._graphs.get(graph_key)
+                if isinstance(ent, dict):
+                    ent["u"].copy_(u)
+                    ent["t"].copy_(tt)
+                    ent["graph"].replay()
+                    return ent["out"].clone().unsqueeze(0)
+
+            def run_cp():
+                self.cp_forwards_issued = getattr(self, "cp_forwards_issued", 0) + 1   # (bench.py --cp-host-probe reports it)
+                # context parallel: local rows only, ONE K/V all-gather per layer (parallel.py).  `local_ranks` is
+                # [rank] in production; a single-process simulation of several ranks runs them in lockstep.
+                from .parallel import shard_rows
+                W, H = cp.world, self.num_heads
+                heads = cp.head_exchange(H)
+                keep = []
+                if heads:
+                    # head exchange: every rank's step addresses the cache heads it owns (the whole cache when it was
+                    # allocated with kv_cache_heads() heads, a head slice of a full-head cache otherwise)
+                    hn = H // W
+                    if kv_cache[0]["k"].shape[2] not in (hn, H):
+                        raise ValueError(f"KV cache must hold {hn} (this rank's) or {H} heads, not {kv_cache[0]['k'].shape[2]}")
+                    parts = []
+                    for i, r in enumerate(cp.local_ranks()):
+                        h0 = 0 if kv_cache[0]["k"].shape[2] == hn else r * hn
+                        ka, kp = ptr_array([c["k"][0, :, h0:h0 + hn] for c in kv_cache])
+                        va, vp = ptr_array([c["v"][0, :, h0:h0 + hn] for c in kv_cache])
+                        keep.append((ka, va))
+                        parts.append(make(shard_rows(M, W, r), i, kp, vp))
+                    bufs = [(r, self._exchange_buffers(M, W, i, u.device)) for i, r in enumerate(cp.local_ranks())]
+                else:
+                    parts = [make(shard_rows(M, W, r), i) for i, r in enumerate(cp.local_ranks())]
                 for st, wsa in parts:
-                    _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)
-                cp.all_gather_rows_(hrow)
-                _lib.call("rtv_dit_finish", cfg_p, ctypes.byref(parts[0][0]), c_vp(hrow.data_ptr()), stream)
+                    _lib.call("rtv_dit_begin", cfg_p, w_p, ctypes.byref(st), *wsa)
+                # Per layer the projection runs in two pieces with the exchange of the first one in flight under the second
+                # (rtv_dit_layer_proj; the collective runs on the process group's communication stream):
+                #   rows  exchange: [LN | K,V] -> all-gather of the new K/V rows (async) -> [Q] -> wait -> attention ...
+                #   heads exchange: [LN | Q]   -> all-to-all(q) (async) -> [K,V] -> all-to-all(k|v) (async) -> wait both -> attention
+                null = c_vp(0)
+                for l in range(L):
+                    last_kv_only = kv_only and l == L - 1      # only the K / V rows of the last layer are still needed
+                    if not heads:
+                        for st, wsa in parts:
+                            _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, 0, null, null, *wsa)
+                        pend = cp.gather_kv(kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
+                        if last_kv_only:
+                            pend.wait()
+                            break
+                        for st, wsa in parts:
+                            _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_Q, 0, null, null, *wsa)
+                        pend.wait()
+                        for st, wsa in parts:
+                            _lib.call("rtv_dit_layer_rest", cfg_p, w_p, ctypes.byref(st), l, *wsa)
+                        continue
+                    if last_kv_only:
+                        for (st, wsa), (_, b) in zip(parts, bufs):
+                            _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_KV, W, null,
+                                      c_vp(b["kv_send"].data_ptr()), *wsa)
+                        cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M)
+                        break
+                    for (st, wsa), (_, b) in zip(parts, bufs):
+                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_LN | PROJ_Q, W,
+                                  c_vp(b["q_send"].data_ptr()), null, *wsa)
+                    pend_q = cp.exchange_q(bufs, async_op=True)
+                    for (st, wsa), (_, b) in zip(parts, bufs):
+                        _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_KV, W, null,
+                                  c_vp(b["kv_send"].data_ptr()), *wsa)
+                    pend_kv = cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
+                    pend_q.wait()
+                    pend_kv.wait()
+                    for (st, wsa), (_, b) in zip(parts, bufs):
+                        _lib.call("rtv_dit_layer_attn_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_all"].data_ptr()),
+                                  c_vp(b["o_all"].data_ptr()), *wsa)
+                    cp.exchange_o(bufs)
+                    for (st, wsa), (_, b) in zip(parts, bufs):
+                        _lib.call("rtv_dit_layer_rest_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["o_recv"].data_ptr()), *wsa)
+                if not kv_only:
+                    hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
+                    for st, wsa in parts:
+                        _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)
+                    cp.all_gather_rows_(hrow)
+                    _lib.call("rtv_dit_finish", cfg_p, ctypes.byref(parts[0][0]), c_vp(hrow.data_ptr()), stream)
+
+            if graph_key is not None and self._graphs.get(graph_key) == "seen":
+                ent = {"u": u.clone(), "t": tt.clone(), "out": out, "keep": (kk_keep, kv_keep, ck_keep, cv_keep)}
+                u, tt = ent["u"], ent["t"]
+                g = torch.cuda.CUDAGraph()
+                if not hasattr(self, "_capture_stream"):
+                    self._capture_stream = torch.cuda.Stream(device=u.device)
+                ops.ensure_gemm_workspace(u.device, self._capture_stream.cuda_stream)
+                # thread_local: the process group's watchdog thread may query its events while this thread captures
+                with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
+                    stream = c_vp(torch.cuda.current_stream().cuda_stream)
+                    run_cp()
+                ent["graph"] = g
+                self._graphs[graph_key] = ent
+                g.replay()
+                return out.clone().unsqueeze(0)
+            if graph_key is not None:
+                self._graphs[graph_key] = "seen"
+            run_cp()
         if need_cross:
             for c in crossattn_cache:
                 c["is_init"] = True

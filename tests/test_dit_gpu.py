@@ -817,6 +817,45 @@ def test_hip_graph_replay_equals_eager():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("exchange", ["heads", "rows"])
+def test_context_parallel_hip_graph_replay_equals_eager(exchange):
+    """r05: the context-parallel forward - per-layer phase calls with the exchanges between them - is captured
+    into hipGraphs like the single-GPU forward (causal_model.py; under RCCL the collectives are recorded by the capture as well:
+    `bench.py --cp-host-probe --hipgraph` on a one-rank NCCL group, profiles/r05_cp_host_probe.txt).  Here: two shards in lockstep
+    in this process (SimulatedContextParallel: the exchanges are block copies), four blocks of the session loop, eager vs graph
+    replay vs the unsharded forward - all bit-identical (tile config 4: no K split, see the test below)."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.parallel import SimulatedContextParallel
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    cfg, text_dim, _ = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    g = torch.Generator().manual_seed(5)
+    padded = torch.zeros(1, 512, text_dim, dtype=torch.bfloat16)
+    padded[0, :64] = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
+    noise = torch.randn(1, 12, 16, 60, 104, generator=g).to(torch.bfloat16)
+    outs = {}
+    for mode in ("plain", "cp", "cp_graph"):
+        model, wr = _build(cfg, text_dim, w)
+        model.gemm_tile_cfg = 4
+        if mode != "plain":
+            model.context_parallel = SimulatedContextParallel(2, exchange)
+        model.use_hip_graphs = mode == "cp_graph"
+        pipe = CausalInferencePipeline(make_args(num_frame_per_block=3), DEV, generator=wr)
+        models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(padded.to(DEV)))
+        sess = GenerationSession(GenerateParams(seed=9, num_blocks=4, num_denoising_steps=4, keep_first_frame=True),
+                                 models, device=DEV)
+        sess.noise = noise.to(DEV)
+        cpu_rnd = torch.Generator().manual_seed(9)
+        sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+        outs[mode] = [sess.generate_block().clone().cpu() for _ in range(4)]
+        if mode == "cp_graph":
+            assert sum(isinstance(v, dict) for v in model._graphs.values()) >= 2    # recompute + denoise step captured
+            assert model.cp_forwards_issued < 4 * 5                                  # the rest were replays
+    for a, b, c in zip(outs["plain"], outs["cp"], outs["cp_graph"]):
+        assert torch.equal(a, b) and torch.equal(b, c)
+
+
 @pytest.mark.parametrize("exchange,tile_cfg", [("heads", 4), ("rows", 4), ("heads", 0)])
 def test_full_width_layer_context_parallel_equals_unsharded(exchange, tile_cfg):
     """BASELINE config 4 at full width: ONE layer of the 14B architecture (d 5120, 40 heads, ffn 13824), 4680 tokens, cache of
