@@ -385,8 +385,9 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
   const int x0 = tx * TW, y0 = ty * TH, n0 = tn * 96;
 
   const int cpk = p.Cin / 32;                      // channel chunks per time slice
-  const int G = 3 * cpk;                           // (dt, chunk) groups
-  const int slice = p.inH * p.inW * p.Cin;
+  const int G = p.kt * cpk;                        // (dt, chunk) groups (kt = 3: causal 3x3x3; kt = 1: the 3x3 conv behind the
+  const int slice = p.inH * p.inW * p.Cin;         //  nearest-2x upsampling, r05)
+  const int taps = 9 * p.kt;
 
   // ---- halo DMA geometry: wave w issues pieces 5w .. 5w+4 (piece 39 repeats 38); lane -> halo pixel q = 16 piece + lane / 4,
   //      LDS slot lane % 4, source chunk = slot ^ key(halo column)
@@ -398,9 +399,14 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
     const int q = piece * 16 + (lane >> 2);
     const int hr = q / HPITCH, hc = q - hr * HPITCH;
     const int y = y0 - 1 + hr, x = x0 - 1 + hc;
-    const bool ok = q < HPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    // p.ups: the conv runs over the nearest-2x upsampled image - halo pixel (y, x) is source pixel (y >> 1, x >> 1); a row window
+    // (row-sharded decode) holds image rows from y_out0 on in the output and from y_in0 on (source resolution) in the input, and
+    // a tap outside the window but inside the image reads its real source row (the caller supplies them)
+    const int yi = p.y_out0 + y;                   // image row
+    const bool ok = q < HPIX && yi >= 0 && yi < p.limH && x >= 0 && x < p.limW;
+    const int ys = p.ups ? (yi >> 1) - p.y_in0 : y, xs = p.ups ? x >> 1 : x;
     const int c = (lane & 3) ^ ((hc >> 2) & 3);
-    h_off[i] = ((t * p.inH + y) * p.inW + x) * p.Cin + c * 8;
+    h_off[i] = ((t * p.inH + ys) * p.inW + xs) * p.Cin + c * 8;
     if (ok) h_ok |= 1 << i;
   }
   // ---- weight DMA geometry: wave w issues pieces 3w .. 3w+2 of the 18 (pieces 18..23 repeat 10..15); piece = (dx, 16 filters)
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
     w_lds[i] = piece * 1024;
     const int dx = piece / 6, f = (piece % 6) * 16 + (lane >> 2);
     const int c = (lane & 3) ^ ((f >> 2) & 3);
-    w_off[i] = ((n0 + f) * 27 + dx) * p.Cin + c * 8;
+    w_off[i] = ((n0 + f) * taps + dx) * p.Cin + c * 8;
   }
   auto issue_h = [&](int g, int i0, int i1) __attribute__((always_inline)) {   // pieces i0..i1-1 of group g's halo
     g = min(g, G - 1);
@@ -612,7 +618,7 @@ static int launch_conv_halo(ConvParams p, hipStream_t stream) {
   const int tiles_x = (p.W + ch::TW - 1) / ch::TW, tiles_y = (p.H + ch::TH - 1) / ch::TH;
   static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
   if (int st = ensure_dynamic_lds((const void*)conv_halo_kernel, ch::LDS_BYTES, &lds_attr, "conv")) return st;
-  ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 27 * p.Cin);
+  ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 9 * p.kt * p.Cin);
   hipLaunchKernelGGL(conv_halo_kernel, dim3(p.T * tiles_y * tiles_x * (p.Cout / 96)), dim3(ch::THREADS), ch::LDS_BYTES, stream, p,
                      tiles_x, tiles_y);
   return check_launch("conv_halo");
@@ -643,11 +649,16 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.n_split && (p.n_split % 4 || p.Cout != 2 * p.n_split)) return set_error(-1, "conv: bad n_split");
   // 3x3x3 stride-1 convs at 96 / 192 / 384 channels: the halo-tile kernel (unless the caller marks the layer RTV_CONV_GATHER).  The choice depends on the layer (channels, taps, layout)
   // only, never on T / H / W: a row-sharded decode must run every layer on the kernel the unsharded one uses (bit parity).
-  const bool halo = g_conv_halo && !p.gather && p.kt == 3 && p.kh == 3 && p.kw == 3 && !p.ups && p.sy == 1 && p.st == 1 && !p.n_split &&
-                    p.pad_h == 1 && p.pad_w == 1 && p.y_out0 == 0 && p.y_in0 == 0 && p.in_rows == p.inH && p.limH == p.inH &&
-                    p.limW == p.inW && p.Cin % 32 == 0 && p.Cin <= 384 && p.Cout % 96 == 0 && p.Cout <= 384 &&
-                    !((p.out_ld | (p.residual ? p.res_ld : 0)) & 7) && !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15) &&
-                    (size_t)(p.T + 2) * p.inH * p.inW * p.Cin < 0x7fffffffull;
+  // r05: also the 3x3 conv behind the nearest-2x upsampling of a Resample (vae_block3.py:19-28, :69-72: 384 -> 192, 384 -> 192, 192 -> 96),
+  // the upsampling folded into the halo gather, with the row windows of the sharded decode.
+  const bool halo_common = g_conv_halo && !p.gather && p.kh == 3 && p.kw == 3 && p.sy == 1 && p.st == 1 && !p.n_split && p.pad_h == 1 &&
+                           p.pad_w == 1 && p.Cin % 32 == 0 && p.Cin <= 384 && p.Cout % 96 == 0 && p.Cout <= 384 &&
+                           !((p.out_ld | (p.residual ? p.res_ld : 0)) & 7) && !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15) &&
+                           (size_t)(p.T + 2) * p.inH * p.inW * p.Cin < 0x7fffffffull;
+  const bool halo3 = halo_common && p.kt == 3 && !p.ups && p.y_out0 == 0 && p.y_in0 == 0 && p.in_rows == p.inH && p.limH == p.inH &&
+                     p.limW == p.inW;
+  const bool halo_up = halo_common && p.kt == 1 && p.ups && p.limW == p.W;
+  const bool halo = halo3 || halo_up;
   if (p.norm_gamma && !(halo && p.Cout == 96 && !p.residual && !((uintptr_t)p.norm_gamma & 7)))
     return set_error(-1, "conv: the fused RMS_norm + SiLU epilogue needs a halo-kernel layer with 96 filters and no residual");
   if (halo) return launch_conv_halo(p, stream);

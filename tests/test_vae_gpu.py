@@ -97,6 +97,20 @@ def test_upsample_conv2d_and_time_conv():
     xin = x.permute(0, 3, 1, 2).float()
     ref = F.conv2d(F.interpolate(xin, scale_factor=(2.0, 2.0), mode="nearest"), w.float(), b.float(), padding=1)
     assert max_abs(out, ref.permute(0, 2, 3, 1)) <= 1e-2
+    # r05: this layer runs on the halo-tile kernel (upsampling folded into the halo gather); RTV_CONV_GATHER keeps it on the
+    # implicit-GEMM gather kernel - same math, another K order (isolated one-ulp fp16 differences); ragged sizes, all three
+    # channel configurations of the decoder's Resample layers, repeated launches bit-identical
+    for (Ci, Co, Tn, Hn, Wn) in ((384, 192, 1, 17, 23), (384, 192, 2, 8, 40), (192, 96, 3, 33, 70)):
+        xx = (torch.randn(Tn, Hn, Wn, Ci, generator=g) * 0.7).half().to(DEV)
+        ww = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).half().to(DEV)
+        bb = (torch.randn(Co, generator=g) * 0.1).half().to(DEV)
+        outs = [_conv_cl(xx, ww, bb, Tn, 2 * Hn, 2 * Wn, 1, 3, 3, ups=1) for _ in range(3)]
+        gat = _conv_cl(xx, ww, bb, Tn, 2 * Hn, 2 * Wn, 1, 3, 3, ups=1 | 16)
+        rf = F.conv2d(F.interpolate(xx.permute(0, 3, 1, 2).float(), scale_factor=(2.0, 2.0), mode="nearest"), ww.float(), bb.float(),
+                      padding=1).permute(0, 2, 3, 1)
+        assert max_abs(outs[0], rf) <= 1e-2 and rel_l2(outs[0], rf) <= 2e-3 and max_abs(gat, rf) <= 1e-2
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert float((gat != outs[0]).float().mean()) <= 5e-3 and max_abs(gat, outs[0]) <= 4e-3
     # time_conv (3,1,1), C -> 2C, channel halves interleaved into frames (vae_block3.py:61-67)
     C = 384
     xc = torch.randn(T + 2, H, W, C, generator=g).half().to(DEV)
