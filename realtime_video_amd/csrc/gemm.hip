@@ -133,6 +133,12 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     const long G = device_num_cus() > 0 ? device_num_cus() : 256;   // the round size plan_split_k uses as well
     const long tail256 = tiles256 % G;
     const bool small_tail = tiles256 > G && tiles256 < 4 * G && tail256 != 0 && tail256 * 4 < G;
+    // r05: up to 8 row tiles of 160 (the token shards of 4- and 8-way context parallelism: 585 / 1170 rows) whose 160 x 256 tiles fill
+    // at least 4/5 of a round run on the one-wave-per-SIMD kernel (gemm5.hip): one round of EQUAL units instead of an under-filled
+    // round of 256-row tiles or 1.17 rounds of 128-row ones - QKV 111 -> 83 us, ffn-in 93 -> 74 at 585 rows, 183 -> 154 / 180 -> 143
+    // at 1170 (hipBLASLt: 95 / 79 / 179 / 236; profiles/r05_gemm5_cp_shapes.log).  Unsplit there: the K order of tile config 4.
+    const long tiles160 = ((p.M + 159) / 160) * tiles_n;
+    if (!f16 && p.K >= 1024 && p.M <= 1280 && tiles160 * 5 >= G * 4) return launch_gemm5(p, f16, true, stream);
     if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < eff256 * 93 || tiles256 * 8 < G * 5 || small_tail))
       return launch_gemm8m(p, f16, true, stream);
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split
@@ -171,6 +177,10 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     case 91:
       return launch_gemm4(p, f16, stream, tile_cfg - 80);   // timing experiments (garbage results)
 #endif
+    case 9:
+      return launch_gemm5(p, f16, true, stream);    // 160x256, one wave per SIMD (few-row problems: context-parallel token shards)
+    case 19:
+      return launch_gemm5(p, f16, false, stream);   // ... without split-K (bit-identical with tile config 4)
     case 6:
       return launch_gemm8m(p, f16, false, stream);  // 128x256 ping-pong kernel (few-row problems), no split-K
     case 7:

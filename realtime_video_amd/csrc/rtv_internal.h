@@ -40,6 +40,7 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
 int launch_gemm8(const GemmParams& p, bool f16, bool split_k, hipStream_t stream);  // 256x256 ping-pong kernel (gemm8.hip)
 int launch_gemm4(const GemmParams& p, bool f16, hipStream_t stream, int lab = 0);   // 256x256, one wave per SIMD, 128x128 per wave (gemm4.hip)
 int launch_gemm8m(const GemmParams& p, bool f16, bool split_k, hipStream_t stream); // its 128x256 variant for few-row problems
+int launch_gemm5(const GemmParams& p, bool f16, bool split_k, hipStream_t stream);  // 160x256, one wave per SIMD (gemm5.hip): token shards
 // fp8 (e4m3) path, gemm_fp8.hip: dynamic per-tensor activation quantisation + 256x256 fp8 GEMM with the bf16 epilogue
 int launch_quantize_fp8(const uint16_t* x, int64_t ld, int M, int d, uint8_t* q, int64_t ldq, float* scale_out,
                         unsigned* amax_scratch, hipStream_t stream);

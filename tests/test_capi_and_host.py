@@ -480,3 +480,17 @@ def test_attn_w4_audit_compiler_stays_out_of_the_accumulation_registers():
     assert re.search(r"\bscratch 0\b", out) and re.search(r"vgpr_spill_count: 0\b", out) and re.search(r"sgpr_spill_count: 0\b", out), out
     assert re.search(r"private_segment_fixed_size: 0\b", out), out
     assert len(re.findall(r"barrier  mfma=64 ", out)) == 4, out
+
+
+def test_gemm5_audit_compiler_stays_out_of_the_live_accumulation_registers():
+    """csrc/gemm5.hip (160-row GEMM of the context-parallel token shards) keeps its accumulators and fragments in accumulation registers
+    named literally in inline asm: scripts/micro/g5_audit.sh compiles it to ISA and counts compiler references to accumulation
+    registers in front of the kernel's last accumulator read-out (behind it they are dead), scratch use and spills - all zero, for
+    the bf16 and the f16 instantiation - and the 3 x 40 matrix instructions of the unrolled K loop."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, G5_AUDIT_DIR=os.path.join(root, "realtime_video_amd", "csrc", "build", "g5_audit"))
+    out = subprocess.run([os.path.join(root, "scripts", "micro", "g5_audit.sh")], capture_output=True, text=True, env=env, timeout=600).stdout
+    assert len(re.findall(r"AUDIT gemm5 F16=\d: vgpr_spills 0 private_segment 0 scratch_ops 0 mfma 120 compiler_acc_refs_before_last_accumulator_read 0 ", out)) == 2, out

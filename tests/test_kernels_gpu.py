@@ -567,6 +567,36 @@ def test_attention_kv_split_matches_unsplit(ops, Lq, Lkv, H, splits, waves):
         ops.attn_fwd_split(q, kc, vc, (0, Lkv), kv_splits=2, workspace=torch.empty(16, dtype=torch.float32, device=DEV))
 
 
+@pytest.mark.parametrize("M,N,K", [(585, 5120, 1024), (585, 15360, 512), (160, 256, 128), (161, 512, 256), (1, 264, 192), (700, 1536, 1536),
+                                   (1170, 13824, 256), (37, 200, 320)])
+def test_gemm_160_row_one_wave_per_simd_kernel_is_bit_identical(ops, M, N, K):
+    """gemm5.hip (r05: 160 x 256 tiles, four waves = one per SIMD, accumulators and fragments in asm-owned accumulation
+    registers - the kernel of the context-parallel token shards): tile config 19 (no split-K) accumulates K in the order of the
+    256 x 256 ping-pong kernel without split-K (tile config 4) and shares its epilogue - bit-identical for every epilogue kind,
+    ragged rows / columns, one-row problems; tile config 9 (K segments where the tiles cannot fill the chip) differs by fp32
+    re-association only and is repeatable (fixed summation order)."""
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    a, w, b = _randn(M, K, seed=1), _randn(N, K, seed=2, scale=K ** -0.5), _randn(N, seed=3, scale=0.1)
+    r = _randn(M, N, seed=4)
+    gate = _randn(3, N, seed=5)
+    for kw in (dict(bias=b), dict(bias=b, act=1), dict(bias=b, gate=gate, gate_stride=N, rows_per_frame=(M + 2) // 3, residual=r), dict()):
+        ref = ops.gemm(a, w, tile_cfg=4, **kw).clone()
+        outs = [ops.gemm(a, w, tile_cfg=19, **kw).clone() for _ in range(3)]
+        assert torch.equal(outs[0], ref) and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        sp = [ops.gemm(a, w, tile_cfg=9, **kw).clone() for _ in range(2)]
+        assert torch.equal(sp[0], sp[1]) and rel_l2(sp[0], ref) <= 2e-3
+
+
+def test_gemm_default_dispatch_takes_the_160_row_kernel_for_token_shards(ops):
+    """The default dispatch (tile config 0) at the row counts of 8- and 4-way context parallelism on the 14B's wide projections
+    (QKV 15360, ffn-in 13824 columns): one round of 160 x 256 tiles, unsplit - i.e. the bits of tile config 4 - where the
+    256- / 128-row kernels would split a tail along K."""
+    ops.ensure_gemm_workspace(torch.device(DEV))
+    for M, N in ((585, 15360), (585, 13824), (1170, 15360)):
+        a, w, b = _randn(M, 1024, seed=1), _randn(N, 1024, seed=2, scale=1024 ** -0.5), _randn(N, seed=3, scale=0.1)
+        assert torch.equal(ops.gemm(a, w, bias=b, tile_cfg=0), ops.gemm(a, w, bias=b, tile_cfg=4))
+
+
 def test_gemm_one_wave_per_simd_config_is_bit_identical(ops):
     """Tile config 8 (gemm4.hip: four waves, 128 x 128 per wave, A by LDS DMA, W through registers) against the production
     ping-pong kernel (config 4) on the layer shapes and ragged ones: same K order per accumulator, same epilogue - bit-identical;
