@@ -51,7 +51,7 @@ def measured_traffic(model):
     --pmc passes).  rocprofv3 --pmc cannot run inside this process, so the committed summary of the newest round is read;
     its sample size and file travel in the JSON line."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(root, "profiles", f"{rnd}_traffic_{model}.json")
         try:
             with open(path) as f:
