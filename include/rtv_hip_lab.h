@@ -19,7 +19,7 @@ extern "C" {
  * 4 waves x 64 rows, asm-owned accumulation registers), ring windows (two row ranges) / f16 on the four-phase kernel (8 waves x
  * 32 rows, K / V by LDS DMA, the two wave groups one phase apart), shorter windows on the lockstep kernel.
  * 4 / 8 = force the workgroup size; 81 / 82 = 256 rows on the lockstep / four-phase schedule; 840 + v = 256 rows on the
- * one-wave-per-SIMD kernel, variant v where it applies (product build: 200 = default, 0; lab build: schedule + 10 x timing experiment +
+ * one-wave-per-SIMD kernel, variant v where it applies (product build: 600 = default, 200, 0; lab build: schedule + 10 x timing experiment +
  * 100 x options, attn_w4.hip).  The lockstep, four-phase and one-wave-per-SIMD (variants without option bit 0) kernels compute
  * every row with the same arithmetic in the same order: bit-identical outputs. */
 int rtv_attn_set_waves(int waves);

@@ -748,7 +748,7 @@ static std::atomic<bool> g_attn_skip_idle{true};  // rtv_attn_set_skip_idle(0): 
 // 256-row launches on the one-wave-per-SIMD kernel (attn_w4.hip): >= 0 a forced kernel variant, -2 = where it applies, its
 // default variant (W4_DEFAULT), -1 = never (rtv_attn_set_waves(81 / 82) pin the older schedules)
 static std::atomic<int> g_attn_w4{-2};
-constexpr int W4_DEFAULT = 200;
+constexpr int W4_DEFAULT = 600;   // plain row sums (bit-identical with the four-phase kernel), one M0 write per operand, output rows through LDS
 namespace rtv {
 int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStream_t stream);   // attn_w4.hip
 }
@@ -759,7 +759,7 @@ extern "C" int rtv_attn_set_skip_idle(int on) {
 }
 
 extern "C" int rtv_attn_set_waves(int waves) {
-  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82 && !(waves >= 840 && waves <= 1239))
+  if (waves != 0 && waves != 4 && waves != 8 && waves != 81 && waves != 82 && !(waves >= 840 && waves <= 1639))
     return set_error(-1, "attn_set_waves: 0 (auto), 4, 8, 81 (256 rows, lockstep schedule), 82 (256 rows, four-phase schedule) or "
                          "840 + v (256 rows, one wave per SIMD, kernel variant v: attn_w4.hip)");
   g_attn_lockstep = waves == 81;

@@ -302,7 +302,7 @@ template <bool F16, int VARL>
 __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
   using namespace w4;
   constexpr int VAR = VARL % 10, LAB = (VARL / 10) % 10, OPT = VARL / 100;
-  constexpr bool RS = OPT & 1, DMA_IMM = OPT & 2;
+  constexpr bool RS = OPT & 1, DMA_IMM = OPT & 2, EPI_LDS = OPT & 4;   // bit 2: output rows through LDS (whole 256-byte rows per store)
   constexpr bool NO_VALU = LAB == 1 || LAB == 6, NO_EXP = LAB == 2, NO_FRAG = LAB == 3 || LAB == 6, NO_DMA = LAB == 4 || LAB == 6,
                  NO_WAIT = LAB == 5 || LAB == 6;
   using SC = Sched<VAR, RS>;
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
       if (i + 3 < n_it) idle_it(IntC<3>{}, i + 3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (EPI_LDS && p.kv_splits <= 1) __syncthreads();   // the working waves' barrier in front of their epilogue image
     return;
   }
 
@@ -758,6 +759,39 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
     else l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
     if (p.kv_splits > 1) {
       store_partial(p, bh, q_row[qb], g, oq, m_run[qb], l_tot);
+    } else if constexpr (EPI_LDS) {
+      // Through a wave-private LDS image of 64 rows x 256 bytes (the K / V rings are dead; this wave's last fragment reads and
+      // DMA pieces have retired - vmcnt(0) above, its reads were consumed - and the image lies in the wave's OWN quarter of the K
+      // ring only if no other wave still reads it: hence the workgroup barrier in front of the first block).  The register layout
+      // gives a lane one row and 4 consecutive dims per quad: stored directly that is 8-byte accesses at a row stride, 32
+      // different cache lines per instruction; from the image every lane stores 16 contiguous bytes and 16 lanes a whole row.
+      // 16-byte chunk c of row r at chunk c ^ (r & 15): the 8-byte writes of 16 consecutive rows and the row-contiguous 16-byte
+      // reads are both conflict-free.
+      const float inv = 1.0f / l_tot;
+      char* img = smem + wave * (64 * 256);
+      if constexpr (qb == 0) __syncthreads();
+      const int row = qb * 32 + l31;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          u32x2 w;
+          w[0] = pack2<F16>(oq[db][4 * i + 0] * inv, oq[db][4 * i + 1] * inv);
+          w[1] = pack2<F16>(oq[db][4 * i + 2] * inv, oq[db][4 * i + 3] * inv);
+          *(u32x2*)(img + row * 256 + (((db * 4 + i) ^ (row & 15)) << 4) + g * 8) = w;
+        }
+      if constexpr (qb == 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int rsub = lane >> 4, cpos = lane & 15;
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+          const int r = ps * 4 + rsub;
+          const u32x4 t = *(const u32x4*)(img + r * 256 + ((cpos ^ (r & 15)) << 4));
+          const int qr = q0 + wave * QW + r;
+          if (qr < p.Lq) *(u32x4*)(ob + (size_t)qr * p.o_rs + cpos * 8) = t;
+        }
+      }
     } else {
       const float inv = 1.0f / l_tot;
       if (q_row[qb] < p.Lq) {
@@ -786,8 +820,8 @@ namespace rtv {
 
 // ---- launcher (called by attn_fwd_impl, attn_fwd.hip): p.n_qtiles = ceil(Lq / 256), grid and split set up by the caller
 int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStream_t stream) {
-  static LdsAttr attr[400];
-  if (variant < 0 || variant >= 400) return set_error(-1, "attn_w4: variant out of range");
+  static LdsAttr attr[800];
+  if (variant < 0 || variant >= 800) return set_error(-1, "attn_w4: variant out of range");
   if (f16) return set_error(-1, "attn_w4: bf16 only (f16 launches stay on the four-phase kernel)");
 #define RTV_W4_CASE(V)                                                                                        \
   case V: {                                                                                                   \
@@ -797,7 +831,8 @@ int launch_attn_w4(const AttnParams& p, bool f16, int variant, dim3 grid, hipStr
     break;                                                                                                    \
   }
   switch (variant) {
-    RTV_W4_CASE(200)   // the product kernel: plain row sums (bit-identical with the four-phase kernel), one M0 write per operand
+    RTV_W4_CASE(600)   // 200 + output rows through LDS
+    RTV_W4_CASE(200)   // plain row sums (bit-identical with the four-phase kernel), one M0 write per operand
     RTV_W4_CASE(0)     // the same with one M0 write per DMA piece
 #ifdef RTV_LAB
     RTV_W4_CASE(100)

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from realtime_video_amd import ops  # noqa: E402
 
 DEV = "cuda"
-VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 100, 300]
+VARIANTS = [int(a) for a in sys.argv[1:]] or [200, 600]
 
 
 def rnd(*shape, seed=0, scale=1.0):

@@ -473,7 +473,7 @@ def test_attn_w4_audit_compiler_stays_out_of_the_accumulation_registers():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, W4_AUDIT_DIR=os.path.join(root, "realtime_video_amd", "csrc", "build", "w4_audit"))
-    out = subprocess.run([os.path.join(root, "scripts", "micro", "w4_audit.sh"), "200"], capture_output=True, text=True, env=env,
+    out = subprocess.run([os.path.join(root, "scripts", "micro", "w4_audit.sh"), "600"], capture_output=True, text=True, env=env,
                          timeout=600).stdout
     assert re.search(r"instructions naming an accumulation register outside asm: 0\b", out), out
     assert re.search(r"v_accvgpr outside asm: 0\b", out), out
