@@ -718,6 +718,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w4_kernel(AttnParams p) {
   lds_wait<0>();
   acc_settle();   // accumulator writes (Q^T, O^T = 0) -> first MFMA
   phase_a(IntC<3>{}, IntC<0>{});
+  // An MFMA result may be read by a VALU instruction 11 wait states behind the MFMA at the earliest, and the compiler does not know
+  // that the asm statements above are MFMAs.  In the tile loop the first reader of S^T(j+1) sits behind the fillers of the last
+  // matrix slot, the scalar limit test, a wait and a PV MFMA that cannot issue before the last QK MFMA has left the pipe; here,
+  // with no PV in between, the distance is made explicit.
+  acc_settle();
   if ((t_lo + 1) * ATT_KT > wave_min_lim) mask_tile(IntC<0>{}, t_lo, false);
   phase_b(IntC<3>{}, IntC<0>{}, lds_wave, tile_soff(t_lo + 3, k_rs), tile_soff(t_lo + 1, v_rs));
   need_any = 0;   // O^T is still zero: nothing to rescale
