@@ -301,7 +301,15 @@ class VAEDecoderWrapperSingle(VAEDecoderWrapper):
     NUM_CACHES = 32
 
     def zero_cache(self, h, w, dtype=torch.float16):
+        """The 32 zero caches of a new stream (demo_utils/constant.py:6-39 at latent size h x w).  In fp16 - what the decoder runs
+        in - they are handed out as views of a fresh, registered arena: the first forward() then finds its arena by lookup and
+        neither allocates nor copies 32 slots of zeros into a new one.  Other dtypes: plain tensors (copied in)."""
         shapes = [(16, 1)] + [(384, 1)] * 11 + [(192, 2)] + [(384, 2)] * 6 + [(192, 4)] * 6 + [(96, 8)] * 7
+        if dtype == torch.float16 and self.row_range(h) == (0, 8 * h):
+            arena = self._new_arena(h, w)                      # zero-filled
+            views = self._cache_views(arena, (-arena.data_ptr()) % 256, h, w)[:self.NUM_CACHES]
+            assert [tuple(v.shape) for v in views] == [(1, c, 2, h * k, w * k) for c, k in shapes]
+            return views
         return [torch.zeros(1, c, 2, h * k, w * k, dtype=dtype, device=self.device) for c, k in shapes]
 
     def forward(self, z, is_first_frame, *feat_cache):

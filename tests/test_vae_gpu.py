@@ -276,12 +276,15 @@ def test_single_frame_decoder_wrapper_matches_reference_golden(golden):
     w16 = {k: v.half().to(DEV) for k, v in vo.make_vae_weights(seed=0).items()}
     zs = vae_inputs(seed=23)[0][:, :3]
     cache = dec.zero_cache(8, 12)
+    arenas0, slot0 = len(dec._arenas._by_ptr), cache[0].data_ptr()      # zero_cache() hands out views of a registered arena ...
     cache16 = vo.single_zero_cache(8, 12, torch.float16, DEV)
     for i in range(3):
         first = torch.tensor([1.0 if i == 0 else 0.0], device=DEV, dtype=torch.float16)     # vae_torch2trt.py:167,174
         if i == 2:
             cache = [c.clone() for c in cache]
         px, cache = dec(zs[:, i:i + 1].half().to(DEV), first, *cache)
+        if i == 0:                                                       # ... which the first call finds: no new arena, no copy-in
+            assert len(dec._arenas._by_ptr) == arenas0 and cache[0].data_ptr() == slot0
         ref = g["pixels"][i]
         assert px.shape == ref.shape == (1, 4, 3, 64, 96) and px.dtype == torch.float32 and len(cache) == 32
         px16, cache16 = vo.decoder_single_forward(w16, zs[:, i:i + 1].half().to(DEV), i == 0, cache16)
