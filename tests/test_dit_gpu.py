@@ -507,6 +507,57 @@ def test_session_long_context_kv_cache_num_frames_9():
     assert kv["k"].shape[1] == 12 * 1560 and kv["local_end_index"] == 12 * 1560 and kv["global_end_index"] == 12 * 1560
 
 
+def test_session_long_form_fp8_window_slides_at_kv_cache_num_frames_9():
+    """BASELINE config 5 put together on one GPU: long-form generation (more blocks than the context window holds, so the
+    recompute pass runs over first frame + the last 8 frames from block 4 on: release_server.py:563-576, :588-633), kv_cache_num_frames
+    = 9, the fp8 weight path (:179-182).  Eight blocks, two layers, tiny width, latents 60 x 104, against the session oracle
+    with the fp8 restatement, and the bf16 session oracle beside it as the scale of the quantisation noise.
+    Tolerance: generation is autoregressive (block b's context is the output of blocks < b), so the two fp8 implementations
+    drift apart by their per-forward difference compounded - stated per block as <= 1.5e-2 and <= the fp8 oracle's own distance
+    from the bf16 oracle at that block (measured: 4.7e-3 .. 7.7e-3 against 1.2e-2 of quantisation noise, flat over the eight
+    blocks); the cache bookkeeping must be exact."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    from realtime_video_amd.session import GenerateParams, GenerationSession, Models, StaticTextEncoder
+    cfg, text_dim, _ = _tiny()
+    cfg["num_layers"] = 2
+    blocks = 8
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    w8 = dict(w)
+    w8[wo.FP8_FLAG] = True
+    g = torch.Generator().manual_seed(21)
+    ctx = torch.randn(64, text_dim, generator=g).to(torch.bfloat16)
+    noise = torch.randn(1, 3 * blocks, 16, 60, 104, generator=g).to(torch.bfloat16)
+    oras = [wo.SessionOracle(_on_dev(ww), cfg, [ctx.to(DEV)], noise.to(DEV), kv_cache_num_frames=9, num_steps=2, shift=5.0, seed=4)
+            for ww in (w8, w)]
+    model, wr = _build(cfg, text_dim, w)
+    model.enable_fp8()
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 500]), DEV, generator=wr,
+                                   text_encoder=None, vae=None)
+    padded = torch.zeros(1, 512, text_dim, dtype=torch.bfloat16)
+    padded[0, :64] = ctx
+    models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(padded.to(DEV)))
+    sess = GenerationSession(GenerateParams(seed=4, num_blocks=blocks, num_denoising_steps=2, kv_cache_num_frames=9,
+                                            keep_first_frame=True), models, device=DEV)
+    sess.noise = noise.to(DEV)
+    cpu_rnd = torch.Generator().manual_seed(4)
+    sess._randn = lambda shape: torch.randn(*shape, generator=cpu_rnd, dtype=torch.bfloat16).to(DEV)
+    report = []
+    for b in range(blocks):
+        out = sess.generate_block().cpu()
+        ref8, ref16 = (o.generate_block().cpu() for o in oras)
+        noise_b = rel_l2(ref8, ref16)
+        report.append((b, rel_l2(out, ref8), noise_b, rel_l2(out, ref16)))
+        print("long-form fp8 c=9 block %d: rel_l2(ours, fp8 oracle) %.3e  (fp8 oracle, bf16 oracle) %.3e  (ours, bf16 oracle) %.3e"
+              % report[-1])
+    for b, d, noise_b, d16 in report:
+        assert d <= 1.5e-2 and d <= noise_b, report
+        assert d16 <= 1.5 * noise_b, report
+    kv = pipe.kv_cache1[0]
+    assert kv["k"].shape[1] == 12 * 1560 and kv["local_end_index"] == 12 * 1560 and kv["global_end_index"] == 12 * 1560
+    assert sess.current_start_frame == 3 * blocks and oras[0].current_start_frame == 3 * blocks
+
+
 def test_session_webcam_v2v_and_prompt_interpolation():
     """Streaming video-to-video (release_server.py:489-527, :651-657): block 0 encodes 9 pushed frames on fresh encoder
     caches (chunks 1+4+4), block 1 encodes 12 with stream=True; denoising starts from latents noised to the first step's
