@@ -531,6 +531,20 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
   CH_FENCE();
 #undef CH_FENCE
 
+  // ---- the residual of this wave's 12 output passes, requested NOW: the passes below otherwise each wait for their own load
+  //      (load -> add -> store, twelve times ~1 us: a third of the kernel on the 96-channel layers, r05 lab builds of the
+  //      one-wave-per-SIMD form); the accumulator conversion runs under the loads' latency instead
+  u32x4 res_pre[2 * 32 * 12 / 64];
+  if (p.residual) {
+#pragma unroll
+    for (int ps = 0; ps < 2 * 32 * 12 / 64; ++ps) {
+      const int q = ps * 64 + lane;
+      const int row = q / 12, c = q - row * 12;
+      const int y = y0 + 2 * wave + (row >> 5), x = x0 + (row & 31);
+      res_pre[ps] = u32x4{0u, 0u, 0u, 0u};
+      if (y < p.H && x < p.W) res_pre[ps] = *(const u32x4*)(p.residual + (((size_t)t * p.H + y) * p.W + x) * p.res_ld + n0 + c * 8);
+    }
+  }
   // ---- epilogue: bias (+ residual) through a wave-private 64 x 96 image (rows of 192 bytes), 16 contiguous bytes per lane.
   //      Fused RMS_norm + SiLU (p.norm_gamma, 96 filters = the whole channel axis of a pixel in this workgroup): lane (l31, gl)
   //      holds 48 of pixel l31's 96 outputs, lane + 32 the other 48 - sum of squares in the lane, one exchange, then
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
     if (y >= p.H || x >= p.W) continue;
     const size_t m = ((size_t)t * p.H + y) * p.W + x;
     if (p.residual) {
-      const u32x4 rr = *(const u32x4*)(p.residual + m * p.res_ld + n);
+      const u32x4 rr = res_pre[ps];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float a0, a1, r0, r1;
@@ -614,13 +628,338 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
   }
 }
 
-static int launch_conv_halo(ConvParams p, hipStream_t stream) {
+// ---------------------------------------------------------------- halo-tile kernel, one wave per SIMD (round 5, lab: rtv_conv_set_halo(2))
+// The same tile, LDS images, DMA pieces, K order and epilogue arithmetic as conv_halo_kernel (bit-identical results), in the
+// one-wave-per-SIMD idiom of attn_w4.hip / gemm5.hip: FOUR waves, wave w = tile rows 4w .. 4w+3 (four 32-pixel m-blocks) x 96
+// filters = 12 accumulator blocks a[0:191]; a (tap, k-step) chunk is 12 MFMAs fed by 7 fragment reads (4 halo + 3 weight blocks)
+// where the two-waves-per-SIMD kernel reads 2 x 5 for the same 12 - 30 % fewer LDS bytes per flop.  Accumulators and the two
+// fragment sets a[192:219] / a[220:247] are named literally in inline asm; the reads of chunk c + 1 sit behind the MFMAs of
+// chunk c (across tap rows too: no drain at a row boundary).  One counted vmcnt + one barrier per tap row, placed behind MFMA 2
+// of the row's LAST chunk: past it every wave has finished the row's reads, so its weight slot takes the row three ahead
+// (two rows of lead) and, after the last row of a group, its halo buffer the group after next (three rows of lead).
+namespace ch4 {
+using namespace ch;
+constexpr int THREADS4 = 256;
+constexpr int HP = 10, WP = 5;                 // halo / weight DMA pieces per wave (pieces past the real ones repeat one)
+constexpr int A_ACC = 0, A_FRAG = 192, FRAG_SET = 28;
+template <int ACC, int WF, int AF>
+__device__ __forceinline__ void mfma_aaa() {
+  asm volatile("v_mfma_f32_32x32x16_f16 a[%c0:%c1], a[%c2:%c3], a[%c4:%c5], a[%c0:%c1]" ::"n"(ACC), "n"(ACC + 15), "n"(WF), "n"(WF + 3),
+               "n"(AF), "n"(AF + 3));
+}
+template <int DST, int OFF>
+__device__ __forceinline__ void lds_read128_a(uint32_t lds_addr) {
+  asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%3" ::"v"(lds_addr), "n"(DST), "n"(DST + 3), "n"(OFF));
+}
+template <int DST>
+__device__ __forceinline__ void acc_zero() {
+  asm volatile("v_accvgpr_write_b32 a[%c0], 0" ::"n"(DST));
+}
+template <int SRC>
+__device__ __forceinline__ float acc_read() {
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(r) : "n"(SRC));
+  return r;
+}
+// (the one clobber list of the kernel: makes the kernel descriptor allocate the accumulation registers it names literally)
+#define RTV_CH4_ACC \
+  "a0", "a15", "a31", "a47", "a63", "a79", "a95", "a111", "a127", "a143", "a159", "a175", "a191", "a207", "a223", "a239", "a247"
+}  // namespace ch4
+
+template <int LAB>   // lab builds (timing only, garbage results): 1 no DMA in the loop, 2 no epilogue, 3 DMA issue staggered by wave (not yet)
+__global__ __launch_bounds__(ch4::THREADS4, 1) void conv_halo4_kernel(ConvParams p, int tiles_x, int tiles_y) {
+  using namespace ch4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, gl = lane >> 5;
+
+  const int tiles_n = p.Cout / 96;
+  const int id = xcd_remap(blockIdx.x, p.T * tiles_y * tiles_x * tiles_n);
+  const int tn = id % tiles_n;
+  int rest = id / tiles_n;
+  const int tx = rest % tiles_x;
+  rest /= tiles_x;
+  const int ty = rest % tiles_y, t = rest / tiles_y;
+  const int x0 = tx * TW, y0 = ty * TH, n0 = tn * 96;
+
+  const int cpk = p.Cin / 32;
+  const int G = p.kt * cpk;
+  const int slice = p.inH * p.inW * p.Cin;
+  const int taps = 9 * p.kt;
+
+  // ---- halo DMA geometry (conv_halo_kernel's pieces, ten per wave): piece -> 16 halo pixels x 64 bytes.  Buffer addressing: the
+  //      per-lane BYTE offset of the pixel's chunk at (dt 0, channel chunk 0) in a VGPR, the group's offset in an SGPR - no vector
+  //      instruction per piece; a pixel outside the image gets an offset beyond the descriptor's end and reads zeros.
+  uint32_t h_voff[HP], h_lds[HP];
+#pragma unroll
+  for (int i = 0; i < HP; ++i) {
+    const int piece = min(wave * HP + i, HREAL - 1);
+    h_lds[i] = piece * 1024;
+    const int q = piece * 16 + (lane >> 2);
+    const int hr = q / HPITCH, hc = q - hr * HPITCH;
+    const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+    const int yi = p.y_out0 + y;
+    const bool ok = q < HPIX && yi >= 0 && yi < p.limH && x >= 0 && x < p.limW;
+    const int ys = p.ups ? (yi >> 1) - p.y_in0 : y, xs = p.ups ? x >> 1 : x;
+    const int c = (lane & 3) ^ ((hc >> 2) & 3);
+    h_voff[i] = ok ? (uint32_t)(((t * p.inH + ys) * p.inW + xs) * p.Cin + c * 8) * 2u : 0x80000000u;
+  }
+  // ---- weight DMA geometry: piece = (dx, 16 filters); wave w issues pieces 5w .. 5w+4 of the 18 (18, 19 repeat 16, 17)
+  uint32_t w_voff[WP], w_lds[WP];
+#pragma unroll
+  for (int i = 0; i < WP; ++i) {
+    int piece = wave * WP + i;
+    if (piece >= WREAL) piece -= 2;
+    w_lds[i] = piece * 1024;
+    const int dx = piece / 6, f = (piece % 6) * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((f >> 2) & 3);
+    w_voff[i] = (uint32_t)(((n0 + f) * taps + dx) * p.Cin + c * 8) * 2u;
+  }
+  const __amdgpu_buffer_rsrc_t rsrcI = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x80000000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(RTV_LDS const char*)smem;
+  // piece I of a halo (byte offset `soff` of its (dt, channel chunk)) -> halo buffer `buf`
+  auto issue_h = [&](uint32_t soff, uint32_t buf, auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    RTV_LDS void* dst = (RTV_LDS void*)(uintptr_t)(lds0 + buf * (uint32_t)HBYTES + h_lds[I]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcI, dst, 16, h_voff[I], soff, 0, 0);
+  };
+  // piece I of a tap row of weights (byte offset `soff` of its (dt, dy, channel chunk)) -> ring slot SLOT
+  auto issue_w = [&](uint32_t soff, auto slotc, auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value, SLOT = decltype(slotc)::value;
+    RTV_LDS void* dst = (RTV_LDS void*)(uintptr_t)(lds0 + (uint32_t)(2 * HBYTES + SLOT * WROW_BYTES) + w_lds[I]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, dst, 16, w_voff[I], soff, 0, 0);
+  };
+  // scalar byte offsets of group g (clamped: groups past the end re-stage the last one into the buffer / slot of THEIR index,
+  // which nobody reads any more): halo (dt, chunk) and tap row (dt, dy, chunk)
+  auto h_soff = [&](int dt, int cb) __attribute__((always_inline)) { return (uint32_t)(dt * slice + cb * 32) * 2u; };
+  auto w_soff = [&](int dt, int cb, int dy) __attribute__((always_inline)) {
+    return (uint32_t)((dt * 9 + dy * 3) * p.Cin + cb * 32) * 2u;
+  };
+
+  // ---- fragment read addresses: halo pixel (row 4 wave + mi + dy [immediate], column l31 + dx), chunk 2 ks + gl; weights:
+  //      ring slot dy (part of the address: an LDS immediate is 16 bits), filter l31, (dx, filter block) immediates
+  uint32_t a_base[3][2], b_addr[3][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hc = l31 + dx;
+      a_base[dx][ks] = lds0 + (uint32_t)(((4 * wave) * HPITCH + hc) * 64 + (((2 * ks + gl) ^ ((hc >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+      b_addr[dy][ks] = lds0 + (uint32_t)(2 * HBYTES + dy * WROW_BYTES + l31 * 64 + (((2 * ks + gl) ^ ((l31 >> 2) & 3)) << 4));
+  }
+  uint32_t a_cur[3][2], a_nxt[3][2];
+  // the 7 reads of chunk (DY, CI) [CI = 2 dx + ks] into fragment set SET: N = 0..2 weight blocks, 3..6 halo rows
+  auto frag_read = [&](auto dyc, auto cic, auto setc, auto nc, const uint32_t (&aa)[3][2]) __attribute__((always_inline)) {
+    constexpr int DY = decltype(dyc)::value, CI = decltype(cic)::value, SET = decltype(setc)::value, N = decltype(nc)::value;
+    constexpr int dx = CI >> 1, ks = CI & 1;
+    if constexpr (N < 3) lds_read128_a<A_FRAG + FRAG_SET * SET + 4 * N, dx * (96 * 64) + N * (32 * 64)>(b_addr[DY][ks]);
+    else lds_read128_a<A_FRAG + FRAG_SET * SET + 12 + 4 * (N - 3), ((N - 3) + DY) * (HPITCH * 64)>(aa[dx][ks]);
+  };
+
+  asm volatile("" ::: RTV_CH4_ACC);
+  sfor<0, 192>([&](auto ic) __attribute__((always_inline)) { acc_zero<A_ACC + decltype(ic)::value>(); });
+
+  // ---- prologue: halo(0), W rows 0 and 1 (row 0 then issues W(2) and halo(1) like every first row of a group); row 0's operands
+  //      landed -> barrier -> the first fragment set
+  sfor<0, HP>([&](auto ic) __attribute__((always_inline)) { issue_h(h_soff(0, 0), 0u, ic); });
+  sfor<0, WP>([&](auto ic) __attribute__((always_inline)) { issue_w(w_soff(0, 0, 0), IC<0>{}, ic); });
+  sfor<0, WP>([&](auto ic) __attribute__((always_inline)) { issue_w(w_soff(0, 0, 1), IC<1>{}, ic); });
+  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // W(1) may still be in flight
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_cur[dx][ks] = a_base[dx][ks];
+  sfor<0, 7>([&](auto nc) __attribute__((always_inline)) { frag_read(IC<0>{}, IC<0>{}, IC<0>{}, nc, a_cur); });
+
+  int dt = 0, cb = 0;   // (time slice, channel chunk) of group g
+  for (int g = 0; g < G; ++g) {
+    const uint32_t nsel = (g & 1) ? 0u : (uint32_t)HBYTES;   // the NEXT group's halo buffer
+    // what this group's three rows stage: W(g, 2), W(g + 1, 0), W(g + 1, 1) and the halo of group g + 1 (clamped to the last)
+    const bool more = g + 1 < G;
+    const int cb1 = cb + 1 == cpk ? 0 : cb + 1, dt1 = cb + 1 == cpk ? dt + 1 : dt;
+    uint32_t ws[3], hs;
+    ws[0] = w_soff(dt, cb, 2);
+    ws[1] = more ? w_soff(dt1, cb1, 0) : ws[0];
+    ws[2] = more ? w_soff(dt1, cb1, 1) : ws[0];
+    hs = more ? h_soff(dt1, cb1) : h_soff(dt, cb);
+    const uint32_t nbuf = (uint32_t)((g + 1) & 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) a_nxt[dx][ks] = a_base[dx][ks] + nsel;
+    sfor<0, 3>([&](auto dyc) __attribute__((always_inline)) {
+      constexpr int DY = decltype(dyc)::value;
+      sfor<0, 6>([&](auto cic) __attribute__((always_inline)) {
+        constexpr int CI = decltype(cic)::value, SET = CI & 1;
+        asm volatile("s_waitcnt lgkmcnt(0)");   // the 7 reads of this chunk (issued behind MFMAs of the previous one)
+        sfor<0, 12>([&](auto nc) __attribute__((always_inline)) {
+          constexpr int n = decltype(nc)::value, mi = n / 3, ni = n % 3;
+          mfma_aaa<A_ACC + (mi * 3 + ni) * 16, A_FRAG + FRAG_SET * SET + 4 * ni, A_FRAG + FRAG_SET * SET + 12 + 4 * mi>();
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (CI < 5) {
+            if constexpr (n < 7) frag_read(dyc, IC<CI + 1>{}, IC<SET ^ 1>{}, nc, a_cur);
+            // the DMA pieces of this epoch (behind the barrier of the previous row): W(row + 2) -> the slot of row - 1 (chunk 0), and
+            // behind the barrier of a group's last row the halo of group g + 1 (row 3g: pieces 0-4 in chunk 1, 5-9 in chunk 2)
+            if constexpr (LAB != 1) {
+              if constexpr (CI == 0 && n >= 7) issue_w(ws[DY], IC<(DY + 2) % 3>{}, IC<n - 7>{});
+              if constexpr (DY == 0 && (CI == 1 || CI == 2) && n >= 7) issue_h(hs, nbuf, IC<(CI - 1) * 5 + n - 7>{});
+            }
+          } else {
+            if constexpr (n == 2) {
+              // every wave's pieces for the next row (and, behind a group's last row, the next group's halo) have landed; younger
+              // pieces stay in flight: DY 0: W(row + 2) 5 + halo(g + 1) 10;  DY 1: the same 15;  DY 2: W(row + 2) 5
+              if constexpr (LAB == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              else if constexpr (DY == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+              else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+              __builtin_amdgcn_s_barrier();
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (n >= 3 && n < 10) {   // chunk 0 of the next tap row
+              if constexpr (DY < 2) frag_read(IC<DY + 1>{}, IC<0>{}, IC<SET ^ 1>{}, IC<n - 3>{}, a_cur);
+              else frag_read(IC<0>{}, IC<0>{}, IC<SET ^ 1>{}, IC<n - 3>{}, a_nxt);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+    });
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) a_cur[dx][ks] = a_nxt[dx][ks];
+    dt = dt1;
+    cb = cb1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)");               // the surplus fragment reads of the last chunk
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ... and DMA pieces: the LDS becomes the epilogue image
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_nop 15\n\ts_nop 7");                // MFMA -> v_accvgpr_read distance
+  if constexpr (LAB == 2) {
+    if (acc_read<0>() == 12345.678f) p.out[tid] = 1;
+    return;
+  }
+
+  // ---- epilogue: conv_halo_kernel's arithmetic, per 32-pixel row block of the wave; wave-private 128 x 96 image.  The residual
+  //      of all 24 output passes is requested first (see conv_halo_kernel).
+  constexpr int TM = 4, TN = 3, CPR = TN * 4;
+  u32x4 res_pre[TM * 32 * CPR / 64];
+  if (p.residual) {
+#pragma unroll
+    for (int ps = 0; ps < TM * 32 * CPR / 64; ++ps) {
+      const int q = ps * 64 + lane;
+      const int row = q / CPR, c = q - row * CPR;
+      const int y = y0 + 4 * wave + (row >> 5), x = x0 + (row & 31);
+      res_pre[ps] = u32x4{0u, 0u, 0u, 0u};
+      if (y < p.H && x < p.W) res_pre[ps] = *(const u32x4*)(p.residual + (((size_t)t * p.H + y) * p.W + x) * p.res_ld + n0 + c * 8);
+    }
+  }
+  char* img = smem + wave * (TM * 32 * TN * 64);
+  sfor<0, TM>([&](auto mic) __attribute__((always_inline)) {
+    constexpr int mi = decltype(mic)::value;
+    f32x16 accv[TN];
+    sfor<0, TN * 16>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      accv[i >> 4][i & 15] = acc_read<A_ACC + mi * 48 + i>();
+    });
+    const int row = mi * 32 + l31;
+    float yv[TN][4][4];
+    float ssq = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int n = n0 + ni * 32 + rq * 8 + gl * 4;
+        float v[4] = {accv[ni][rq * 4 + 0], accv[ni][rq * 4 + 1], accv[ni][rq * 4 + 2], accv[ni][rq * 4 + 3]};
+        if (p.bias) {
+          const u32x2 bb = *(const u32x2*)(p.bias + n);
+          v[0] += f16_to_f32(bb[0] & 0xffff);
+          v[1] += f16_to_f32(bb[0] >> 16);
+          v[2] += f16_to_f32(bb[1] & 0xffff);
+          v[3] += f16_to_f32(bb[1] >> 16);
+        }
+        u32x2 o;
+        o[0] = pack_f16x2(v[0], v[1]);
+        o[1] = pack_f16x2(v[2], v[3]);
+        if (p.norm_gamma) {
+          unpack_f16x2(o[0], yv[ni][rq][0], yv[ni][rq][1]);
+          unpack_f16x2(o[1], yv[ni][rq][2], yv[ni][rq][3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ssq += yv[ni][rq][i] * yv[ni][rq][i];
+        } else {
+          *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gl)) = o;
+        }
+      }
+    if (p.norm_gamma) {
+      ssq += __shfl_xor(ssq, 32, 64);
+      const float inv = sqrtf(96.f) / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+      for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const u32x2 gg = *(const u32x2*)(p.norm_gamma + ni * 32 + rq * 8 + gl * 4);
+          float g4[4];
+          unpack_f16x2(gg[0], g4[0], g4[1]);
+          unpack_f16x2(gg[1], g4[2], g4[3]);
+          float z[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[i] = silu(yv[ni][rq][i] * inv * g4[i]);
+          u32x2 o;
+          o[0] = pack_f16x2(z[0], z[1]);
+          o[1] = pack_f16x2(z[2], z[3]);
+          *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gl)) = o;
+        }
+    }
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  constexpr int PASSES = TM * 32 * CPR / 64;
+#pragma unroll
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int q = ps * 64 + lane;
+    const int row = q / CPR, c = q - row * CPR;
+    const int y = y0 + 4 * wave + (row >> 5), x = x0 + (row & 31);
+    const int n = n0 + c * 8;
+    u32x4 tv = *(const u32x4*)(img + conv_img_off<TN>(row, c, 0));
+    if (y >= p.H || x >= p.W) continue;
+    const size_t m = ((size_t)t * p.H + y) * p.W + x;
+    if (p.residual) {
+      const u32x4 rr = res_pre[ps];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a0, a1, r0, r1;
+        unpack_f16x2(tv[i], a0, a1);
+        unpack_f16x2(rr[i], r0, r1);
+        tv[i] = pack_f16x2(a0 + r0, a1 + r1);
+      }
+    }
+    *(u32x4*)(p.out + m * p.out_ld + n) = tv;
+  }
+}
+
+static int launch_conv_halo(ConvParams p, hipStream_t stream, int form) {   // form 0: two waves per SIMD; 1: one (lab build: 2, 3 = timing forms of it)
   const int tiles_x = (p.W + ch::TW - 1) / ch::TW, tiles_y = (p.H + ch::TH - 1) / ch::TH;
-  static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
-  if (int st = ensure_dynamic_lds((const void*)conv_halo_kernel, ch::LDS_BYTES, &lds_attr, "conv")) return st;
+  static LdsAttr lds_attr[4];   // per device (a second GPU used from this process needs the attribute as well)
+  const void* kern = form == 1 ? (const void*)conv_halo4_kernel<0> : (const void*)conv_halo_kernel;
+#ifdef RTV_LAB
+  if (form == 2) kern = (const void*)conv_halo4_kernel<1>;
+  if (form == 3) kern = (const void*)conv_halo4_kernel<2>;
+#endif
+  if (int st = ensure_dynamic_lds(kern, ch::LDS_BYTES, &lds_attr[form], "conv")) return st;
   ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 9 * p.kt * p.Cin);
-  hipLaunchKernelGGL(conv_halo_kernel, dim3(p.T * tiles_y * tiles_x * (p.Cout / 96)), dim3(ch::THREADS), ch::LDS_BYTES, stream, p,
-                     tiles_x, tiles_y);
+  const dim3 grid(p.T * tiles_y * tiles_x * (p.Cout / 96));
+  if (form == 1) hipLaunchKernelGGL(conv_halo4_kernel<0>, grid, dim3(ch4::THREADS4), ch::LDS_BYTES, stream, p, tiles_x, tiles_y);
+#ifdef RTV_LAB
+  else if (form == 2) hipLaunchKernelGGL(conv_halo4_kernel<1>, grid, dim3(ch4::THREADS4), ch::LDS_BYTES, stream, p, tiles_x, tiles_y);
+  else if (form == 3) hipLaunchKernelGGL(conv_halo4_kernel<2>, grid, dim3(ch4::THREADS4), ch::LDS_BYTES, stream, p, tiles_x, tiles_y);
+#endif
+  else hipLaunchKernelGGL(conv_halo_kernel, grid, dim3(ch::THREADS), ch::LDS_BYTES, stream, p, tiles_x, tiles_y);
   return check_launch("conv_halo");
 }
 
@@ -639,7 +978,9 @@ static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   return check_launch("conv");
 }
 
-static std::atomic<bool> g_conv_halo{true};   // rtv_conv_set_halo(0): A/B against conv_igemm_kernel (lab / tests)
+// rtv_conv_set_halo: 0 = conv_igemm_kernel everywhere (A/B, tests); 1 = default: the halo-tile kernels, per layer the faster form;
+// 2 / 3 = the one- / two-waves-per-SIMD form wherever a halo kernel applies (lab build: 4, 5 = timing-only forms of the former)
+static std::atomic<int> g_conv_halo{1};
 
 int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.M <= 0) return 0;
@@ -661,7 +1002,14 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   const bool halo = halo3 || halo_up;
   if (p.norm_gamma && !(halo && p.Cout == 96 && !p.residual && !((uintptr_t)p.norm_gamma & 7)))
     return set_error(-1, "conv: the fused RMS_norm + SiLU epilogue needs a halo-kernel layer with 96 filters and no residual");
-  if (halo) return launch_conv_halo(p, stream);
+  if (halo) {
+    // one wave per SIMD from 192 input channels on (3x3x3; behind an upsampling from 384): +3..9 % there (12+ channel-chunk groups per
+    // tile), level or behind at 96, where a tile's epilogue weighs as much as its K loop (profiles/r05_conv_halo4.log).  By LAYER only -
+    // never by T / H / W (see above).
+    const int mode = g_conv_halo;
+    const int form = mode == 1 ? ((p.kt == 3 && p.Cin >= 192) || p.Cin >= 384 ? 1 : 0) : mode == 2 ? 1 : mode == 3 ? 0 : mode - 2;
+    return launch_conv_halo(p, stream, form);
+  }
   if (p.Cout % 96 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 96, 32, 2, 1>(p, stream);
   if (p.Cout <= 32) return launch_conv_cfg<128, 32, 32, 2, 1>(p, stream);
   return launch_conv_cfg<128, 128, 32, 2, 2>(p, stream);
@@ -672,7 +1020,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
 using namespace rtv;
 
 extern "C" int rtv_conv_set_halo(int on) {
-  g_conv_halo = on != 0;
+#ifdef RTV_LAB
+  g_conv_halo = on < 0 || on > 5 ? 1 : on;
+#else
+  g_conv_halo = on < 0 || on > 3 ? 1 : on;
+#endif
   return 0;
 }
 

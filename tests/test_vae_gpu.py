@@ -87,6 +87,57 @@ def test_halo_conv_kernel_edges_and_gather_flag(Cin, Cout, T, H, W):
         assert float((gather != outs[0]).float().mean()) <= 5e-3 and max_abs(gather, outs[0]) <= 4e-3
 
 
+def test_halo_conv_kernel_forms_are_bit_identical():
+    """The halo-tile kernel exists in two forms - two waves per SIMD (conv_halo_kernel, eight waves, 64 x 96 per wave) and one wave
+    per SIMD (conv_halo4_kernel, r05: four waves, 128 x 96 per wave, accumulation registers named in inline asm) - with the same
+    tile, K order and epilogue arithmetic; the default picks one per LAYER (input channels), so both must give the same bits on
+    every layer kind: 3x3x3 with bias / residual / neither, ragged tiles, one to twelve channel chunks per slice, the 3x3 conv
+    behind the nearest-2x upsampling, the fused RMS_norm + SiLU epilogue.  Repeated launches of the new form bit-identical."""
+    from realtime_video_amd import _lib
+    from realtime_video_amd.vae_decoder import pack_conv_weight
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(77)
+    zeros = torch.zeros(64, dtype=torch.float16, device=DEV)
+
+    def both(fn):
+        outs = {}
+        try:
+            for mode in (3, 2, 2):                      # two waves per SIMD, one wave per SIMD (twice)
+                lib.rtv_conv_set_halo(mode)
+                outs.setdefault(mode, []).append(fn())
+        finally:
+            lib.rtv_conv_set_halo(1)
+        assert torch.isfinite(outs[3][0].float()).all()
+        assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][0], outs[2][1])
+
+    for (Cin, Cout, T, H, W) in ((96, 96, 2, 33, 70), (32, 96, 1, 16, 32), (192, 384, 3, 17, 31), (384, 192, 1, 48, 64),
+                                 (96, 192, 4, 5, 100), (192, 192, 2, 64, 96)):
+        x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.7).half().to(DEV)
+        w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
+        b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
+        res = torch.randn(T, H, W, Cout, generator=g).half().to(DEV)
+        for bias, residual in ((b, res), (None, None), (b, None)):
+            both(lambda: _conv_cl(x, w, bias, T, H, W, 3, 3, 3, residual=residual))
+    for (Ci, Co, Tn, Hn, Wn) in ((384, 192, 1, 17, 23), (384, 192, 2, 8, 40), (192, 96, 3, 33, 70)):
+        xx = (torch.randn(Tn, Hn, Wn, Ci, generator=g) * 0.7).half().to(DEV)
+        ww = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).half().to(DEV)
+        bb = (torch.randn(Co, generator=g) * 0.1).half().to(DEV)
+        both(lambda: _conv_cl(xx, ww, bb, Tn, 2 * Hn, 2 * Wn, 1, 3, 3, ups=1))
+    for (Cin, T, H, W) in ((96, 2, 33, 70), (384, 1, 5, 9)):     # fused RMS_norm + SiLU epilogue (96 filters)
+        x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.7).half().to(DEV)
+        wp = pack_conv_weight((torch.randn(96, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half()).to(DEV)
+        b = (torch.randn(96, generator=g) * 0.1).half().to(DEV)
+        gamma = (1.0 + 0.2 * torch.randn(96, generator=g)).half().to(DEV)
+
+        def fused():
+            out = torch.full((T, H, W, 96), float("nan"), dtype=torch.float16, device=DEV)
+            fn = lib.rtv_conv3_norm_silu_cl
+            fn.argtypes = _lib.EXTRA_SIGNATURES["rtv_conv3_norm_silu_cl"]
+            assert fn(_p(x), _p(wp), _p(b), _p(gamma), _p(out), 96, T, H, W, Cin, 96, 0, _p(zeros), _stream()) == 0
+            return out
+        both(fused)
+
+
 def test_upsample_conv2d_and_time_conv():
     g = torch.Generator().manual_seed(3)
     T, H, W, C = 2, 6, 10, 192
