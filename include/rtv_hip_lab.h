@@ -40,10 +40,10 @@ int rtv_conv_set_fuse_norm(int on);
  * Bit-identical. */
 int rtv_attn_set_skip_idle(int on);
 /* VAE 3x3x3 stride-1 convolutions (and the 3x3 ones behind a nearest-2x upsampling): 0 = the implicit-GEMM gather kernel everywhere;
- * 1 (default) = the halo-tile kernels, per layer the faster of the two forms (one wave per SIMD from 192 input channels on);
- * 2 / 3 = the one- / two-waves-per-SIMD form wherever a halo kernel applies.  The two halo forms are bit-identical with each other
- * (same K order, same epilogue arithmetic); the gather kernel sums a pixel's taps in another order (0.03-0.06 % of the fp16 outputs
- * differ by one rounding).  Lab build: 4 / 5 = timing-only forms of 2 (no DMA in the loop / no epilogue; garbage results). */
+ * 1 (default) = 6 = the persistent one-wave-per-SIMD halo-tile kernel; 2 / 3 = the one- / two-waves-per-SIMD halo kernel with one
+ * workgroup per tile.  The three halo forms are bit-identical with each other (same K order, same epilogue arithmetic); the gather
+ * kernel sums a pixel's taps in another order (0.03-0.25 % of the fp16 outputs differ by one rounding).  Lab build: 4 / 5 =
+ * timing-only forms of 2 (no DMA in the loop / no epilogue; garbage results). */
 int rtv_conv_set_halo(int on);
 /* RMSNorm(q,k) + RoPE + cache-write kernel: -1 = by row count (default), 0 = one 256-thread workgroup per row, 1 = two waves per row.
  * Bit-identical: both forms sum a row's squares in ONE canonical order (four accumulators per lane column, combined, then the

@@ -943,17 +943,364 @@ __global__ __launch_bounds__(ch4::THREADS4, 1) void conv_halo4_kernel(ConvParams
   }
 }
 
-static int launch_conv_halo(ConvParams p, hipStream_t stream, int form) {   // form 0: two waves per SIMD; 1: one (lab build: 2, 3 = timing forms of it)
+// ---------------------------------------------------------------- ... and PERSISTENT (round 5): one workgroup per CU walks its tiles
+// (virtual block ids b, b + gridDim, ..: the ids the hardware would have dispatched to this CU's XCD) and the operand stream never
+// stops: where conv_halo4_kernel re-stages its last group past the end of a tile, this kernel stages the first group of its NEXT tile,
+// so a tile boundary is just another group boundary of the (halo double buffer, weight ring) pipeline - no prologue, no dispatch gap,
+// and the output stores of a tile drain under the next tile's matrix instructions.  At a boundary the wave reads its 12 accumulator
+// blocks out (and zeroes them) one 32-pixel row at a time through a wave-private 6 KiB image in the 24 KiB of LDS the pipeline leaves
+// free.  Same K order and epilogue arithmetic: bit-identical with the other two forms.
+// Stores count in vmcnt and are not ordered against loads: the first barrier of a tile waits for vmcnt(0).
+__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 2))) void conv_halo4p_kernel(ConvParams p, int tiles_x,
+                                                                                                                      int tiles_y) {
+  using namespace ch4;
+  // accumulation-register map of THIS kernel: a[0:7] are left to the compiler (with a tile loop around the K loop hipcc parks a few
+  // loop-carried values there; scripts/micro/h4_audit.sh checks that it touches nothing above a7), accumulators a[8:199], fragment sets
+  // a[200:227] / a[228:255]
+  constexpr int A_ACC = 8, A_FRAG = 200;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, gl = lane >> 5;
+
+  const int tiles_n = p.Cout / 96;
+  const int total = p.T * tiles_y * tiles_x * tiles_n;
+  const int stride = gridDim.x;
+  const int cpk = p.Cin / 32;
+  const int G = p.kt * cpk;
+  const int slice = p.inH * p.inW * p.Cin;
+  const int taps = 9 * p.kt;
+
+  auto decode = [&](int vid, int& t, int& y0, int& x0, int& n0) __attribute__((always_inline)) {
+    const int id = xcd_remap(vid, total);
+    const int tn = id % tiles_n;
+    int rest = id / tiles_n;
+    const int tx = rest % tiles_x;
+    rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    t = rest / tiles_y;
+    x0 = tx * TW;
+    y0 = ty * TH;
+    n0 = tn * 96;
+  };
+  // DMA geometry of a tile (conv_halo4_kernel's): per-lane byte offsets of the ten halo pieces and five weight pieces of this wave
+  uint32_t h_lds[HP], w_lds[WP];
+#pragma unroll
+  for (int i = 0; i < HP; ++i) h_lds[i] = min(wave * HP + i, HREAL - 1) * 1024;
+#pragma unroll
+  for (int i = 0; i < WP; ++i) w_lds[i] = (wave * WP + i >= WREAL ? wave * WP + i - 2 : wave * WP + i) * 1024;
+  auto tile_voff = [&](int t, int y0, int x0, int n0, uint32_t (&hv)[HP], uint32_t (&wv)[WP]) __attribute__((always_inline)) {
+    int lane_v = lane, wave_v = wave;   // (laundered: see the epilogue)
+    asm volatile("" : "+v"(lane_v), "+s"(wave_v));
+#pragma unroll
+    for (int i = 0; i < HP; ++i) {
+      const int piece = min(wave_v * HP + i, HREAL - 1);
+      const int q = piece * 16 + (lane_v >> 2);
+      const int hr = q / HPITCH, hc = q - hr * HPITCH;
+      const int y = y0 - 1 + hr, x = x0 - 1 + hc;
+      const int yi = p.y_out0 + y;
+      const bool ok = q < HPIX && yi >= 0 && yi < p.limH && x >= 0 && x < p.limW;
+      const int ys = p.ups ? (yi >> 1) - p.y_in0 : y, xs = p.ups ? x >> 1 : x;
+      const int c = (lane_v & 3) ^ ((hc >> 2) & 3);
+      hv[i] = ok ? (uint32_t)(((t * p.inH + ys) * p.inW + xs) * p.Cin + c * 8) * 2u : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < WP; ++i) {
+      int piece = wave_v * WP + i;
+      if (piece >= WREAL) piece -= 2;
+      const int dx = piece / 6, f = (piece % 6) * 16 + (lane_v >> 2);
+      const int c = (lane_v & 3) ^ ((f >> 2) & 3);
+      wv[i] = (uint32_t)(((n0 + f) * taps + dx) * p.Cin + c * 8) * 2u;
+    }
+  };
+  const __amdgpu_buffer_rsrc_t rsrcI = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x80000000, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7fffffff, 0x00020000);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(RTV_LDS const char*)smem;
+  auto issue_h = [&](uint32_t soff, uint32_t buf, uint32_t voff, auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    RTV_LDS void* dst = (RTV_LDS void*)(uintptr_t)(lds0 + buf * (uint32_t)HBYTES + h_lds[I]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcI, dst, 16, voff, soff, 0, 0);
+  };
+  auto issue_w = [&](uint32_t soff, auto slotc, uint32_t voff, auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value, SLOT = decltype(slotc)::value;
+    RTV_LDS void* dst = (RTV_LDS void*)(uintptr_t)(lds0 + (uint32_t)(2 * HBYTES + SLOT * WROW_BYTES) + w_lds[I]);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcW, dst, 16, voff, soff, 0, 0);
+  };
+  auto h_soff = [&](int dt, int cb) __attribute__((always_inline)) { return (uint32_t)(dt * slice + cb * 32) * 2u; };
+  auto w_soff = [&](int dt, int cb, int dy) __attribute__((always_inline)) {
+    return (uint32_t)((dt * 9 + dy * 3) * p.Cin + cb * 32) * 2u;
+  };
+
+  // fragment read addresses (conv_halo4_kernel's), recomputed per tile from a laundered lane id: nothing but scalars stays live
+  // across a tile's epilogue, which then has the whole architectural file to itself (see the note there)
+  uint32_t a_base[3][2], b_addr[3][2];
+  auto frag_addrs = [&]() __attribute__((always_inline)) {
+    int lane_k = lane, wave_k = wave;
+    asm volatile("" : "+v"(lane_k), "+s"(wave_k));
+    const int l31k = lane_k & 31, glk = lane_k >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int hc = l31k + dx;
+        a_base[dx][ks] = lds0 + (uint32_t)(((4 * wave_k) * HPITCH + hc) * 64 + (((2 * ks + glk) ^ ((hc >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+        b_addr[dy][ks] = lds0 + (uint32_t)(2 * HBYTES + dy * WROW_BYTES + l31k * 64 + (((2 * ks + glk) ^ ((l31k >> 2) & 3)) << 4));
+    }
+  };
+  frag_addrs();
+  uint32_t a_cur[3][2], a_nxt[3][2];
+  auto frag_read = [&](auto dyc, auto cic, auto setc, auto nc, const uint32_t (&aa)[3][2]) __attribute__((always_inline)) {
+    constexpr int DY = decltype(dyc)::value, CI = decltype(cic)::value, SET = decltype(setc)::value, N = decltype(nc)::value;
+    constexpr int dx = CI >> 1, ks = CI & 1;
+    if constexpr (N < 3) lds_read128_a<A_FRAG + FRAG_SET * SET + 4 * N, dx * (96 * 64) + N * (32 * 64)>(b_addr[DY][ks]);
+    else lds_read128_a<A_FRAG + FRAG_SET * SET + 12 + 4 * (N - 3), ((N - 3) + DY) * (HPITCH * 64)>(aa[dx][ks]);
+  };
+
+  asm volatile("" ::: RTV_CH4_ACC, "a255");
+  sfor<0, 192>([&](auto ic) __attribute__((always_inline)) { acc_zero<A_ACC + decltype(ic)::value>(); });
+
+  int vid = blockIdx.x;
+  int ct, cy0, cx0, cn0;                 // the tile being accumulated
+  uint32_t hv_c[HP], wv_c[WP], hv_n[HP], wv_n[WP];   // its DMA geometry, and the next tile's
+  decode(vid, ct, cy0, cx0, cn0);
+  tile_voff(ct, cy0, cx0, cn0, hv_c, wv_c);
+
+  // ---- prologue of the FIRST tile: halo(0), W rows 0 and 1 -> barrier -> the first fragment set
+  sfor<0, HP>([&](auto ic) __attribute__((always_inline)) { issue_h(h_soff(0, 0), 0u, hv_c[decltype(ic)::value], ic); });
+  sfor<0, WP>([&](auto ic) __attribute__((always_inline)) { issue_w(w_soff(0, 0, 0), IC<0>{}, wv_c[decltype(ic)::value], ic); });
+  sfor<0, WP>([&](auto ic) __attribute__((always_inline)) { issue_w(w_soff(0, 0, 1), IC<1>{}, wv_c[decltype(ic)::value], ic); });
+  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  uint32_t par = 0u;                      // halo buffer of the current group
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) a_cur[dx][ks] = a_base[dx][ks];
+  sfor<0, 7>([&](auto nc) __attribute__((always_inline)) { frag_read(IC<0>{}, IC<0>{}, IC<0>{}, nc, a_cur); });
+
+  for (bool first_tile = true;; first_tile = false) {
+    const bool has_next = vid + stride < total;
+    if (!first_tile) {   // (everything per-lane is rebuilt here rather than carried through the previous tile's epilogue)
+      frag_addrs();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) a_cur[dx][ks] = a_base[dx][ks] + par * (uint32_t)HBYTES;
+      tile_voff(ct, cy0, cx0, cn0, hv_c, wv_c);
+    }
+    {
+      int nt = ct, ny0 = cy0, nx0 = cx0, nn0 = cn0;   // (no next tile: its slots are filled with this tile's first group again; nobody reads them)
+      if (has_next) decode(vid + stride, nt, ny0, nx0, nn0);
+      tile_voff(nt, ny0, nx0, nn0, hv_n, wv_n);
+    }
+    int dt = 0, cb = 0;   // (time slice, channel chunk) of group g
+    for (int g = 0; g < G; ++g) {
+      // what this group's three rows stage: W(g, 2), then rows 0 and 1 and the halo of the NEXT group - of this tile, or group 0 of the next
+      const bool last = g + 1 == G;
+      const int cb1 = last ? 0 : (cb + 1 == cpk ? 0 : cb + 1), dt1 = last ? 0 : (cb + 1 == cpk ? dt + 1 : dt);
+      uint32_t ws[3], hs;
+      ws[0] = w_soff(dt, cb, 2);
+      ws[1] = w_soff(dt1, cb1, 0);
+      ws[2] = w_soff(dt1, cb1, 1);
+      hs = h_soff(dt1, cb1);
+      const uint32_t nbuf = par ^ 1u;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) a_nxt[dx][ks] = a_base[dx][ks] + nbuf * (uint32_t)HBYTES;
+      sfor<0, 3>([&](auto dyc) __attribute__((always_inline)) {
+        constexpr int DY = decltype(dyc)::value;
+        sfor<0, 6>([&](auto cic) __attribute__((always_inline)) {
+          constexpr int CI = decltype(cic)::value, SET = CI & 1;
+          asm volatile("s_waitcnt lgkmcnt(0)");   // the 7 reads of this chunk (issued behind MFMAs of the previous one)
+          sfor<0, 12>([&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value, mi = n / 3, ni = n % 3;
+            mfma_aaa<A_ACC + (mi * 3 + ni) * 16, A_FRAG + FRAG_SET * SET + 4 * ni, A_FRAG + FRAG_SET * SET + 12 + 4 * mi>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CI < 5) {
+              if constexpr (n < 7) frag_read(dyc, IC<CI + 1>{}, IC<SET ^ 1>{}, nc, a_cur);
+              if constexpr (CI == 0 && n >= 7) {
+                if constexpr (DY == 0) issue_w(ws[0], IC<2>{}, wv_c[n - 7], IC<n - 7>{});
+                else issue_w(ws[DY], IC<DY - 1>{}, last ? wv_n[n - 7] : wv_c[n - 7], IC<n - 7>{});
+              }
+              if constexpr (DY == 0 && (CI == 1 || CI == 2) && n >= 7)
+                issue_h(hs, nbuf, last ? hv_n[(CI - 1) * 5 + n - 7] : hv_c[(CI - 1) * 5 + n - 7], IC<(CI - 1) * 5 + n - 7>{});
+            } else {
+              if constexpr (n == 2) {
+                if constexpr (DY == 2) {
+                  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                } else if constexpr (DY == 1) {
+                  asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                } else {
+                  if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous tile's output stores are in the count
+                  else asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              if constexpr (n >= 3 && n < 10) {   // chunk 0 of the next tap row
+                if constexpr (DY < 2) frag_read(IC<DY + 1>{}, IC<0>{}, IC<SET ^ 1>{}, IC<n - 3>{}, a_cur);
+                else frag_read(IC<0>{}, IC<0>{}, IC<SET ^ 1>{}, IC<n - 3>{}, a_nxt);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      });
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) a_cur[dx][ks] = a_nxt[dx][ks];
+      par = nbuf;
+      dt = dt1;
+      cb = cb1;
+    }
+
+    // ---- the tile's epilogue (conv_halo_kernel's arithmetic), one 32-pixel row of the wave at a time through a wave-private 32 x 96
+    //      image; the fragment reads of the next tile's first chunk and its DMA pieces stay in flight
+    asm volatile("s_nop 15\n\ts_nop 7");   // MFMA -> v_accvgpr_read distance
+    {
+      constexpr int TN = 3, CPR = TN * 4, PPM = 32 * CPR / 64;   // 6 store passes per row block
+      // (lane and wave laundered: everything the epilogue derives from them is invariant over the tile loop, and hipcc would hoist
+      //  some 150 registers of store addresses out of it - over the whole K loop, into the accumulation file this kernel owns)
+      int lane_e = lane, wave_e = wave;
+      asm volatile("" : "+v"(lane_e), "+s"(wave_e));
+      const int l31e = lane_e & 31, gle = lane_e >> 5;
+      char* img = smem + LDS_BYTES + wave_e * (32 * TN * 64);
+      u32x2 bias_pre[TN * 4];
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < TN * 4; ++j) bias_pre[j] = *(const u32x2*)(p.bias + cn0 + (j >> 2) * 32 + (j & 3) * 8 + gle * 4);
+      }
+      u32x4 res_pre[PPM];   // the residual of the row block being converted (requested before its conversion)
+      auto res_load = [&](auto mic) __attribute__((always_inline)) {
+        constexpr int mi = decltype(mic)::value;
+#pragma unroll
+        for (int ps = 0; ps < PPM; ++ps) {
+          const int q = ps * 64 + lane_e;
+          const int row = q / CPR, c = q - row * CPR;
+          const int y = min(cy0 + 4 * wave_e + mi, p.H - 1), x = min(cx0 + row, p.W - 1);   // (pixels past the image: clamped, never stored)
+          res_pre[ps] = *(const u32x4*)(p.residual + (((size_t)ct * p.H + y) * p.W + x) * p.res_ld + cn0 + c * 8);
+        }
+      };
+      if (p.residual) res_load(IC<0>{});
+      sfor<0, 4>([&](auto mic) __attribute__((always_inline)) {
+        constexpr int mi = decltype(mic)::value;
+        f32x16 accv[TN];
+        sfor<0, TN * 16>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int i = decltype(ic)::value;
+          accv[i >> 4][i & 15] = acc_read<A_ACC + mi * 48 + i>();
+        });
+        sfor<0, TN * 16>([&](auto ic) __attribute__((always_inline)) { acc_zero<A_ACC + mi * 48 + decltype(ic)::value>(); });
+        const int row = l31e;
+        u32x2 ypk[TN * 4];   // norm path: the fp16-rounded conv outputs, packed (unpacked again for the second pass: 24 registers, not 48)
+        float ssq = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            float v[4] = {accv[ni][rq * 4 + 0], accv[ni][rq * 4 + 1], accv[ni][rq * 4 + 2], accv[ni][rq * 4 + 3]};
+            if (p.bias) {
+              const u32x2 bb = bias_pre[ni * 4 + rq];
+              v[0] += f16_to_f32(bb[0] & 0xffff);
+              v[1] += f16_to_f32(bb[0] >> 16);
+              v[2] += f16_to_f32(bb[1] & 0xffff);
+              v[3] += f16_to_f32(bb[1] >> 16);
+            }
+            u32x2 o;
+            o[0] = pack_f16x2(v[0], v[1]);
+            o[1] = pack_f16x2(v[2], v[3]);
+            if (p.norm_gamma) {
+              float y4[4];
+              unpack_f16x2(o[0], y4[0], y4[1]);
+              unpack_f16x2(o[1], y4[2], y4[3]);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ssq += y4[i] * y4[i];
+              ypk[ni * 4 + rq] = o;
+            } else {
+              *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gle)) = o;
+            }
+          }
+        if (p.norm_gamma) {
+          ssq += __shfl_xor(ssq, 32, 64);
+          const float inv = sqrtf(96.f) / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+          for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+              const u32x2 gg = *(const u32x2*)(p.norm_gamma + ni * 32 + rq * 8 + gle * 4);
+              float g4[4], y4[4];
+              unpack_f16x2(gg[0], g4[0], g4[1]);
+              unpack_f16x2(gg[1], g4[2], g4[3]);
+              unpack_f16x2(ypk[ni * 4 + rq][0], y4[0], y4[1]);
+              unpack_f16x2(ypk[ni * 4 + rq][1], y4[2], y4[3]);
+              float z[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) z[i] = silu(y4[i] * inv * g4[i]);
+              u32x2 o;
+              o[0] = pack_f16x2(z[0], z[1]);
+              o[1] = pack_f16x2(z[2], z[3]);
+              *(u32x2*)(img + conv_img_off<TN>(row, ni * 4 + rq, gle)) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ps = 0; ps < PPM; ++ps) {
+          const int q = ps * 64 + lane_e;
+          const int r = q / CPR, c = q - r * CPR;
+          const int y = cy0 + 4 * wave_e + mi, x = cx0 + r;
+          const int n = cn0 + c * 8;
+          u32x4 tv = *(const u32x4*)(img + conv_img_off<TN>(r, c, 0));
+          if (y >= p.H || x >= p.W) continue;
+          const size_t m = ((size_t)ct * p.H + y) * p.W + x;
+          if (p.residual) {
+            const u32x4 rr = res_pre[ps];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float a0, a1, r0, r1;
+              unpack_f16x2(tv[i], a0, a1);
+              unpack_f16x2(rr[i], r0, r1);
+              tv[i] = pack_f16x2(a0 + r0, a1 + r1);
+            }
+          }
+          *(u32x4*)(p.out + m * p.out_ld + n) = tv;
+        }
+        if constexpr (mi + 1 < 4) {
+          if (p.residual) res_load(IC<mi + 1>{});
+        }
+      });
+    }
+    if (!has_next) break;
+    vid += stride;
+    decode(vid, ct, cy0, cx0, cn0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA piece may land in this LDS after the workgroup has left
+}
+
+static int launch_conv_halo(ConvParams p, hipStream_t stream, int form) {   // form 0: two waves per SIMD; 1: one; 4: one, persistent (lab build: 2, 3 = timing forms of 1)
   const int tiles_x = (p.W + ch::TW - 1) / ch::TW, tiles_y = (p.H + ch::TH - 1) / ch::TH;
-  static LdsAttr lds_attr[4];   // per device (a second GPU used from this process needs the attribute as well)
-  const void* kern = form == 1 ? (const void*)conv_halo4_kernel<0> : (const void*)conv_halo_kernel;
+  static LdsAttr lds_attr[5];   // per device (a second GPU used from this process needs the attribute as well)
+  const void* kern = form == 1 ? (const void*)conv_halo4_kernel<0> : form == 4 ? (const void*)conv_halo4p_kernel : (const void*)conv_halo_kernel;
 #ifdef RTV_LAB
   if (form == 2) kern = (const void*)conv_halo4_kernel<1>;
   if (form == 3) kern = (const void*)conv_halo4_kernel<2>;
 #endif
-  if (int st = ensure_dynamic_lds(kern, ch::LDS_BYTES, &lds_attr[form], "conv")) return st;
+  const int lds = form == 4 ? ch::LDS_BYTES + 4 * 32 * 192 : ch::LDS_BYTES;   // persistent form: + four wave-private 32 x 96 epilogue images
+  if (int st = ensure_dynamic_lds(kern, lds, &lds_attr[form], "conv")) return st;
   ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 9 * p.kt * p.Cin);
   const dim3 grid(p.T * tiles_y * tiles_x * (p.Cout / 96));
+  if (form == 4) {   // one workgroup per CU, rounded down to whole XCD rows so that a virtual id keeps its XCD (id % 8)
+    const int cus = device_num_cus() > 0 ? device_num_cus() : 256;
+    const int nwg = (int)grid.x < cus ? (int)grid.x : cus / 8 * 8;
+    hipLaunchKernelGGL(conv_halo4p_kernel, dim3(nwg), dim3(ch4::THREADS4), lds, stream, p, tiles_x, tiles_y);
+    return check_launch("conv_halo");
+  }
   if (form == 1) hipLaunchKernelGGL(conv_halo4_kernel<0>, grid, dim3(ch4::THREADS4), ch::LDS_BYTES, stream, p, tiles_x, tiles_y);
 #ifdef RTV_LAB
   else if (form == 2) hipLaunchKernelGGL(conv_halo4_kernel<1>, grid, dim3(ch4::THREADS4), ch::LDS_BYTES, stream, p, tiles_x, tiles_y);
@@ -978,8 +1325,8 @@ static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   return check_launch("conv");
 }
 
-// rtv_conv_set_halo: 0 = conv_igemm_kernel everywhere (A/B, tests); 1 = default: the halo-tile kernels, per layer the faster form;
-// 2 / 3 = the one- / two-waves-per-SIMD form wherever a halo kernel applies (lab build: 4, 5 = timing-only forms of the former)
+// rtv_conv_set_halo: 0 = conv_igemm_kernel everywhere (A/B, tests); 1 = default = 6: the persistent one-wave-per-SIMD halo kernel;
+// 2 / 3 = the one- / two-waves-per-SIMD form with one workgroup per tile (lab build: 4, 5 = timing-only forms of 2)
 static std::atomic<int> g_conv_halo{1};
 
 int launch_conv(const ConvParams& p, hipStream_t stream) {
@@ -1003,11 +1350,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (p.norm_gamma && !(halo && p.Cout == 96 && !p.residual && !((uintptr_t)p.norm_gamma & 7)))
     return set_error(-1, "conv: the fused RMS_norm + SiLU epilogue needs a halo-kernel layer with 96 filters and no residual");
   if (halo) {
-    // one wave per SIMD from 192 input channels on (3x3x3; behind an upsampling from 384): +3..9 % there (12+ channel-chunk groups per
-    // tile), level or behind at 96, where a tile's epilogue weighs as much as its K loop (profiles/r05_conv_halo4.log).  By LAYER only -
-    // never by T / H / W (see above).
+    // default: the persistent one-wave-per-SIMD form on every layer a halo kernel takes (-8..11 % against the two-waves form on
+    // all thirteen decoder layer shapes, profiles/r05_conv_halo4.log).  The choice is by LAYER only - never by T / H / W (see above) -
+    // and the three forms are bit-identical anyway.
     const int mode = g_conv_halo;
-    const int form = mode == 1 ? ((p.kt == 3 && p.Cin >= 192) || p.Cin >= 384 ? 1 : 0) : mode == 2 ? 1 : mode == 3 ? 0 : mode - 2;
+    const int form = mode == 1 || mode == 6 ? 4 : mode == 2 ? 1 : mode == 3 ? 0 : mode - 2;
     return launch_conv_halo(p, stream, form);
   }
   if (p.Cout % 96 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 96, 32, 2, 1>(p, stream);
@@ -1021,9 +1368,9 @@ using namespace rtv;
 
 extern "C" int rtv_conv_set_halo(int on) {
 #ifdef RTV_LAB
-  g_conv_halo = on < 0 || on > 5 ? 1 : on;
+  g_conv_halo = on < 0 || on > 6 ? 1 : on;
 #else
-  g_conv_halo = on < 0 || on > 3 ? 1 : on;
+  g_conv_halo = on < 0 || (on > 3 && on != 6) ? 1 : on;
 #endif
   return 0;
 }

@@ -44,8 +44,8 @@ shapes = [(96, 96, 4, 480, 832), (192, 192, 4, 240, 416), (96, 96, 4, 60, 832), 
           (384, 384, 4, 120, 208), (384, 384, 2, 120, 208), (384, 384, 1, 60, 104), (192, 384, 4, 120, 208), (384, 384, 4, 15, 208),
           # nearest-2x + Conv2d 3x3 (Resample): output dims; no residual
           (384, 192, 2, 120, 208, "ups"), (384, 192, 4, 240, 416, "ups"), (192, 96, 4, 480, 832, "ups")]
-MODES = (3, 2, 0) + ((4, 5) if lib.rtv_lab_build() else ())      # rtv_conv_set_halo: two waves per SIMD, one, gather (, lab forms)
-NAMES = {3: "halo", 2: "halo4", 0: "gather", 4: "h4-noDMA", 5: "h4-noEpi"}
+MODES = (3, 2, 6, 0) + ((4, 5) if lib.rtv_lab_build() else ())      # rtv_conv_set_halo: two waves per SIMD, one, one + persistent, gather (, lab forms)
+NAMES = {3: "halo", 2: "halo4", 6: "halo4p", 0: "gather", 4: "h4-noDMA", 5: "h4-noEpi"}
 zeros = torch.zeros(64, dtype=torch.float16, device=DEV)
 with torch.backends.cudnn.flags(enabled=False):
     for si, shp in enumerate(shapes):
@@ -76,7 +76,7 @@ with torch.backends.cudnn.flags(enabled=False):
                 d = (outs[halo].float() - ref).abs().max().item()
                 line += f"max|{NAMES[halo]} - fp32| {d:.2e}  "
         line += f"halo, gather differ in {(outs[3] != outs[0]).float().mean().item() * 100:.3f} % of the outputs; "
-        line += f"halo4 == halo: {torch.equal(outs[2], outs[3])}; "
+        line += f"halo4 == halo4p == halo: {torch.equal(outs[2], outs[3]) and torch.equal(outs[6], outs[3])}; "
         t = {m: [] for m in MODES}
         for _ in range(rounds):
             for halo in MODES:

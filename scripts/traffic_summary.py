@@ -14,7 +14,7 @@ import sys
 CLASSES = [
     ("gemm", ("gemm8_kernel<false", "gemm_kernel<false", "gemm5_kernel<false")),       # bf16 DiT projection GEMMs
     ("attn", ("attn_fwd_kernel", "attn_fwd_pp_kernel", "attn_fwd_w4_kernel")),
-    ("conv", ("conv_igemm_kernel", "conv_halo_kernel", "gemm_kernel<true", "gemm8_kernel<true")),  # fp16: VAE
+    ("conv", ("conv_igemm_kernel", "conv_halo", "gemm_kernel<true", "gemm8_kernel<true")),  # fp16: VAE
     ("layernorm", ("layernorm_modulate_kernel",)),
     ("rope", ("qk_norm_rope_cache_kernel",)),
 ]

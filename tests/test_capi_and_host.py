@@ -494,3 +494,21 @@ def test_gemm5_audit_compiler_stays_out_of_the_live_accumulation_registers():
     env = dict(os.environ, G5_AUDIT_DIR=os.path.join(root, "realtime_video_amd", "csrc", "build", "g5_audit"))
     out = subprocess.run([os.path.join(root, "scripts", "micro", "g5_audit.sh")], capture_output=True, text=True, env=env, timeout=600).stdout
     assert len(re.findall(r"AUDIT gemm5 F16=\d: vgpr_spills 0 private_segment 0 scratch_ops 0 mfma 120 compiler_acc_refs_before_last_accumulator_read 0 ", out)) == 2, out
+
+
+def test_conv_halo4_audit_compiler_stays_out_of_the_accumulation_registers():
+    """csrc/vae_conv.hip: the one-wave-per-SIMD halo-tile convolution kernels (conv_halo4_kernel, and conv_halo4p_kernel - the
+    persistent form, the VAE's default) keep 12 accumulator blocks and two fragment sets in accumulation registers named literally
+    in inline asm.  scripts/micro/h4_audit.sh compiles the file to ISA and counts, per kernel, compiler references to accumulation
+    registers (the persistent form has a tile loop around its K loop: everything per-lane is rebuilt per tile from laundered ids so
+    that hipcc has no loop-carried values to park there), scratch use and vector-register spills - all zero - and the 216 matrix
+    instructions of a group of three tap rows."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, H4_AUDIT_DIR=os.path.join(root, "realtime_video_amd", "csrc", "build", "h4_audit"))
+    out = subprocess.run([os.path.join(root, "scripts", "micro", "h4_audit.sh")], capture_output=True, text=True, env=env, timeout=600).stdout
+    pat = (r"AUDIT _ZN3rtv1[78]conv_halo4p?_kernel\S*: arch_vgprs \d+ vgpr_spills 0 sgpr_spills \d+ private_segment 0 scratch_ops 0 "
+           r"mfma 216 compiler_acc_refs 0 \(a0-a7: 0\)")
+    assert len(re.findall(pat, out)) == 2, out

@@ -88,11 +88,13 @@ def test_halo_conv_kernel_edges_and_gather_flag(Cin, Cout, T, H, W):
 
 
 def test_halo_conv_kernel_forms_are_bit_identical():
-    """The halo-tile kernel exists in two forms - two waves per SIMD (conv_halo_kernel, eight waves, 64 x 96 per wave) and one wave
-    per SIMD (conv_halo4_kernel, r05: four waves, 128 x 96 per wave, accumulation registers named in inline asm) - with the same
-    tile, K order and epilogue arithmetic; the default picks one per LAYER (input channels), so both must give the same bits on
-    every layer kind: 3x3x3 with bias / residual / neither, ragged tiles, one to twelve channel chunks per slice, the 3x3 conv
-    behind the nearest-2x upsampling, the fused RMS_norm + SiLU epilogue.  Repeated launches of the new form bit-identical."""
+    """The halo-tile kernel exists in three forms - two waves per SIMD (conv_halo_kernel, eight waves, 64 x 96 per wave), one wave
+    per SIMD (conv_halo4_kernel, r05: four waves, 128 x 96 per wave, accumulation registers named in inline asm) and the latter
+    PERSISTENT (conv_halo4p_kernel, the default: one workgroup per CU walks its tiles, the operand stream runs across tile
+    boundaries, the epilogue goes through 24 KiB of spare LDS) - with the same tile, K order and epilogue arithmetic: the same bits
+    on every layer kind: 3x3x3 with bias / residual / neither, ragged tiles, one to twelve channel chunks per slice, more tiles
+    than CUs (several tiles per workgroup) and fewer, the 3x3 conv behind the nearest-2x upsampling, the fused RMS_norm + SiLU
+    epilogue.  Repeated launches bit-identical."""
     from realtime_video_amd import _lib
     from realtime_video_amd.vae_decoder import pack_conv_weight
     lib = _lib.load()
@@ -102,16 +104,17 @@ def test_halo_conv_kernel_forms_are_bit_identical():
     def both(fn):
         outs = {}
         try:
-            for mode in (3, 2, 2):                      # two waves per SIMD, one wave per SIMD (twice)
+            for mode in (3, 2, 6, 6):                   # two waves per SIMD, one wave per SIMD, persistent (twice)
                 lib.rtv_conv_set_halo(mode)
                 outs.setdefault(mode, []).append(fn())
         finally:
             lib.rtv_conv_set_halo(1)
         assert torch.isfinite(outs[3][0].float()).all()
-        assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][0], outs[2][1])
+        assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[6][0], outs[3][0]) and torch.equal(outs[6][0], outs[6][1])
 
     for (Cin, Cout, T, H, W) in ((96, 96, 2, 33, 70), (32, 96, 1, 16, 32), (192, 384, 3, 17, 31), (384, 192, 1, 48, 64),
-                                 (96, 192, 4, 5, 100), (192, 192, 2, 64, 96)):
+                                 (96, 192, 4, 5, 100), (192, 192, 2, 64, 96),
+                                 (96, 96, 3, 200, 330)):     # 3 x 13 x 11 = 429 tiles: up to two per workgroup, ragged on both axes
         x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.7).half().to(DEV)
         w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
         b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
