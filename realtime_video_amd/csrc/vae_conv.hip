@@ -1354,7 +1354,9 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     // all thirteen decoder layer shapes, profiles/r05_conv_halo4.log).  The choice is by LAYER only - never by T / H / W (see above) -
     // and the three forms are bit-identical anyway.
     const int mode = g_conv_halo;
-    const int form = mode == 1 || mode == 6 ? 4 : mode == 2 ? 1 : mode == 3 ? 0 : mode - 2;
+    int form = mode == 1 || mode == 6 ? 4 : mode == 2 ? 1 : mode == 3 ? 0 : mode - 2;
+    // the one-wave forms address the input through a buffer descriptor with 32-bit BYTE offsets and an out-of-image sentinel at 2^31
+    if (form != 0 && (size_t)(p.T + 2) * p.inH * p.inW * p.Cin * 2 >= 0x80000000ull) form = 0;
     return launch_conv_halo(p, stream, form);
   }
   if (p.Cout % 96 == 0 && p.Cout % 128 != 0) return launch_conv_cfg<128, 96, 32, 2, 1>(p, stream);
