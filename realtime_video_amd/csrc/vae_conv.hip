@@ -208,6 +208,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
   const bool wide = !((p.out_ld | (p.residual ? p.res_ld : 0) | p.n_split) & 7) &&
                     !(((uintptr_t)p.out | (uintptr_t)p.residual) & 15);
   if (wide) {
+    // the residual of this wave's output passes, requested ahead of the accumulator conversion (otherwise every pass waits for its own
+    // load: r05, see conv_halo_kernel)
+    constexpr int NPASS = TM * 32 * CPR / 64;
+    u32x4 res_pre[NPASS];
+    if (p.residual) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int q = ps * 64 + lane;
+        const int row = q / CPR, c = q - row * CPR;
+        const int m = min(m0 + a_row0 + row, p.M - 1), n = min(n0 + b_row0 + c * 8, p.Cout - 8);   // (clamped: rows / chunks past the end are never stored)
+        res_pre[ps] = *(const u32x4*)(p.residual + (size_t)m * p.res_ld + n);
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
       const int row = mi * 32 + l31;
@@ -248,7 +261,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
       }
       if (m >= p.M || n >= p.Cout) continue;
       if (p.residual) {
-        const u32x4 rr = *(const u32x4*)(p.residual + (size_t)m * p.res_ld + n);
+        const u32x4 rr = res_pre[ps];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float a0, a1, r0, r1;
