@@ -114,14 +114,15 @@ def test_halo_conv_kernel_forms_are_bit_identical():
 
     for (Cin, Cout, T, H, W) in ((96, 96, 2, 33, 70), (32, 96, 1, 16, 32), (192, 384, 3, 17, 31), (384, 192, 1, 48, 64),
                                  (96, 192, 4, 5, 100), (192, 192, 2, 64, 96),
-                                 (96, 96, 3, 200, 330)):     # 3 x 13 x 11 = 429 tiles: up to two per workgroup, ragged on both axes
+                                 (96, 96, 3, 200, 330),      # 3 x 13 x 11 = 429 tiles: up to two per workgroup, ragged on both axes, 9 groups per tile
+                                 (192, 96, 2, 200, 330)):    # 286 tiles of 18 groups (the halo buffer parity continues across a tile boundary either way)
         x = (torch.randn(T + 2, H, W, Cin, generator=g) * 0.7).half().to(DEV)
         w = (torch.randn(Cout, Cin, 3, 3, 3, generator=g) * (27 * Cin) ** -0.5).half().to(DEV)
         b = (torch.randn(Cout, generator=g) * 0.1).half().to(DEV)
         res = torch.randn(T, H, W, Cout, generator=g).half().to(DEV)
         for bias, residual in ((b, res), (None, None), (b, None)):
             both(lambda: _conv_cl(x, w, bias, T, H, W, 3, 3, 3, residual=residual))
-    for (Ci, Co, Tn, Hn, Wn) in ((384, 192, 1, 17, 23), (384, 192, 2, 8, 40), (192, 96, 3, 33, 70)):
+    for (Ci, Co, Tn, Hn, Wn) in ((384, 192, 1, 17, 23), (384, 192, 2, 8, 40), (192, 96, 3, 33, 70), (192, 96, 4, 80, 160)):   # the last: 400 tiles
         xx = (torch.randn(Tn, Hn, Wn, Ci, generator=g) * 0.7).half().to(DEV)
         ww = (torch.randn(Co, Ci, 3, 3, generator=g) * (9 * Ci) ** -0.5).half().to(DEV)
         bb = (torch.randn(Co, generator=g) * 0.1).half().to(DEV)
