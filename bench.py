@@ -237,6 +237,9 @@ def main():
     if os.environ.get("RTV_ROPE_WAVE") is not None:      # A/B of the RoPE / cache kernel forms (include/rtv_hip_lab.h), diagnostic
         from realtime_video_amd import _lib
         _lib.load().rtv_rope_set_wave(int(os.environ["RTV_ROPE_WAVE"]))
+    if os.environ.get("RTV_DIRECT_V") is not None:       # A/B of the V cache write (GEMM epilogue vs copy, include/rtv_hip_lab.h), diagnostic
+        from realtime_video_amd import _lib
+        _lib.load().rtv_dit_set_direct_v(int(os.environ["RTV_DIRECT_V"]))
     mc = MODELS[args.model]
     model = CausalWanModel(dim=mc["dim"], ffn_dim=mc["ffn_dim"], num_heads=mc["num_heads"], num_layers=mc["num_layers"],
                            text_dim=4096, freq_dim=256, device=dev).init_random_weights(seed=0)

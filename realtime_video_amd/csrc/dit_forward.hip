@@ -13,6 +13,8 @@
 // shard flips to heads - each rank attends ALL M query rows for its H/world heads over a KV cache that holds only those
 // heads.  Two all-to-alls per layer (q|k|v out, attention output back) move 4*(M/world)*d*(world-1)/world elements per
 // rank instead of the all-gather's 2*M*d*(world-1)/world: world/2 times less xGMI traffic.
+#include <atomic>
+
 #include "rtv_common.h"
 #include "rtv_internal.h"
 
@@ -215,6 +217,7 @@ static int hp_check(Ctx& c, int world);
 // `parts` selects what this call does, so that the host can put a collective between the two projections and let it run
 // under the other one (RTV_PROJ_*): LN (the shared input of both), Q (columns [0, d) of the fused QKV weight), KV (columns
 // [d, 3d)).  q_send / kv_send non-null = head-parallel exchange buffers (see below), null = local q + cache rows.
+static std::atomic<int> g_direct_v{1};   // rtv_dit_set_direct_v(0): the V cache rows are copied by the RoPE / cache kernel (r04 form; A/B, tests)
 static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, void* kv_send) {
   const rtv_dit_layer_weights& lw = c.w->layers[l];
   const rtv_dit_step* st = c.st;
@@ -231,12 +234,36 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
   const uint16_t* wq = (const uint16_t*)lw.qkv_w;
   const uint16_t* bq = (const uint16_t*)lw.qkv_b;
   const size_t welt = c.cfg->use_fp8 ? 1 : 2;   // fp8 weights are bytes
+  bool v_in_place = false;
   {
     const void* wp = (const char*)lw.qkv_w + (size_t)n0 * d * welt;
     (void)wq;
     if (!c.cfg->use_fp8) {
-      RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, nn, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc,
-                       c.stream));
+      // r05: when this call's cache rows are ONE physical row range (always, unless a ring write wraps), the V third of the projection
+      // is written into the V cache by the GEMM's epilogue; the RoPE / cache kernel then moves a third less (rope_parts | 4)
+      void* v_dst = nullptr;
+      if (kv && !kv_send && g_direct_v.load(std::memory_order_relaxed) && st->kv_v[l] && !(st->kv_row_stride & 7)) {
+        int r0 = st->cache_row0 + c.r0;
+        const int S = st->ring_lo, R = st->ring_size;
+        bool one_range = true;
+        if (R > 0 && r0 + c.rc > S) {
+          if (r0 < S) one_range = false;                          // sink rows and ring rows in one call
+          else {
+            r0 = S + (r0 - S + st->ring_shift) % R;
+            one_range = r0 + c.rc <= S + R;
+          }
+        }
+        uint16_t* dst = (uint16_t*)st->kv_v[l] + (size_t)r0 * st->kv_row_stride;
+        if (one_range && !((uintptr_t)dst & 15)) v_dst = dst;
+      }
+      if (v_dst) {
+        RTV_TRY(gemm_two_outputs(b.xn, d, wp, d, b.qkv + n0, 3 * d, v_dst, (int)st->kv_row_stride, 2 * d - n0, c.rc, nn, d, bq + n0, 0, nullptr,
+                                 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc, c.stream));
+        v_in_place = true;
+      } else {
+        RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, nn, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc,
+                         c.stream));
+      }
     } else {
       if (!c.w->fp8_scales) return set_error(-1, "dit: use_fp8 needs rtv_dit_weights.fp8_scales");
       if (rtv_quantize_fp8(b.xn, d, c.rc, d, b.q8, d, b.fscale, b.fscale + 1, c.stream)) return -1;
@@ -244,7 +271,7 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
                            bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, c.stream));
     }
   }
-  const int rope_parts = (q ? 1 : 0) | (kv ? 2 : 0);
+  const int rope_parts = (q ? 1 : 0) | (kv ? 2 : 0) | (v_in_place ? 4 : 0);
   if (q_send || kv_send) {
     RTV_TRY(hp_check(c, world));
     const int gc = d / world;
@@ -493,4 +520,9 @@ extern "C" int rtv_dit_forward(const rtv_dit_config* cfg, const rtv_dit_weights*
   }
   RTV_TRY(dit_head(c, c.b.hrow));
   return rtv_unpatchify(c.b.hrow, st->out, cfg->out_dim, c.F, c.gh, c.gw, stream);
+}
+
+extern "C" int rtv_dit_set_direct_v(int on) {
+  g_direct_v = on ? 1 : 0;
+  return 0;
 }

@@ -171,7 +171,8 @@ struct RopeArgs {
   // rolling cache as a ring: logical cache row r >= ring_lo lives at ring_lo + (r - ring_lo + ring_shift) % ring_size
   // (ring_size == 0: no ring, logical == physical); rows below ring_lo are the attention-sink rows and never move.
   int ring_lo, ring_size, ring_shift;
-  int parts;   // bit 0: process q, bit 1: process k and v (the split projection of the context-parallel overlap; 3 = all)
+  int parts;   // bit 0: process q, bit 1: process k and v (the split projection of the context-parallel overlap; 3 = all);
+               // bit 2 (with bit 1): V is in the cache already (written there by the projection GEMM, r05) - no copy
 };
 
 // rotate the 4 complex pairs of one 8-element chunk by the (cos, sin) values in w[0..4)
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(EW_THREADS) __attribute__((amdgpu_waves_per_eu(CPL 
     }
   }
   // V is a plain copy into the cache; this wave moves its half of the row's chunks while its own vector is in flight
-  if (do_kv) {
+  if (do_kv && !(a.parts & 4)) {
     constexpr int VH = (CPL + 1) / 2;
     const int i0 = role * VH;
     u32x4 vraw[VH];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_block_kernel(Ro
       }
       if (do_kv) {
         unpack_bf16x8(*(const u32x4*)(kr + c * 8), k[i]);
-        vraw[i] = *(const u32x4*)(vr + c * 8);
+        if (!(a.parts & 4)) vraw[i] = *(const u32x4*)(vr + c * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) sk = __builtin_fmaf(k[i][j], k[i][j], sk);
       }
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(EW_THREADS) void qk_norm_rope_cache_block_kernel(Ro
         for (int j = 0; j < 8; ++j) k[i][j] = round_bf16(round_bf16(k[i][j] * rk) * wk8[j]);
         rope8_cols(k[i], c * 8, a.hd, c0, c1, pos_f, pos_h, pos_w, a.rope_cs);
         *(u32x4*)(ko + g * a.kv_group_stride + col) = pack_bf16x8(k[i]);
-        *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
+        if (!(a.parts & 4)) *(u32x4*)(vo + g * a.kv_group_stride + col) = vraw[i];
       }
     }
   }
@@ -494,7 +495,7 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
                         int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
                         int parts, rtv_stream_t stream) {
   if (M <= 0) return 0;
-  if (parts < 1 || parts > 3) return set_error(-1, "qk_norm_rope_cache: parts must be 1 (q), 2 (k, v) or 3");
+  if (parts < 1 || parts > 7 || parts == 4 || parts == 5) return set_error(-1, "qk_norm_rope_cache: parts must be 1 (q), 2 (k, v) or 3 (+ 4: V in place)");
   if (ring_size < 0 || ring_lo < 0 || ring_shift < 0 || (ring_size > 0 && ring_shift >= ring_size))
     return set_error(-1, "qk_norm_rope_cache: bad ring (need ring_lo >= 0, 0 <= ring_shift < ring_size)");
   if (ring_size > 0 && cache_row0 + row_offset + M > ring_lo + ring_size)
@@ -534,7 +535,7 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   a.ring_size = ring_size;
   a.ring_shift = ring_shift;
   a.parts = parts;
-  ProfScope prof(PROF_ROPE, (hipStream_t)stream, (parts == 3 ? 6.0 : parts == 1 ? 2.0 : 4.0) * M * d * 2);
+  ProfScope prof(PROF_ROPE, (hipStream_t)stream, ((parts & 1 ? 2.0 : 0.0) + (parts & 2 ? (parts & 4 ? 2.0 : 4.0) : 0.0)) * M * d * 2);
   const int g_sel = g_rope_wave.load(std::memory_order_relaxed);
   if (g_sel == 0 || (g_sel < 0 && M < ROPE_WAVE_MIN_ROWS)) {
     hipLaunchKernelGGL(qk_norm_rope_cache_block_kernel, dim3(M), dim3(EW_THREADS), 0, (hipStream_t)stream, a);

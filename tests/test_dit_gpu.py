@@ -676,6 +676,48 @@ def test_config1_320x192_native_block_and_vae():
     assert rel_l2(sess.all_latents.cpu(), ref) <= 5e-2
 
 
+def test_v_cache_rows_written_by_the_projection_gemm_equal_the_copied_ones():
+    """r05: the V third of the fused QKV projection goes into the V cache from the GEMM's epilogue (gemm_two_outputs, dit_forward.hip)
+    whenever the call's cache rows are one physical range; the RoPE / cache kernel then skips its V copy.  Pure data movement: flow
+    prediction and the whole K / V cache must equal the r04 form (rtv_dit_set_direct_v(0): V copied out of the projection output) bit
+    for bit - a denoise step at cache offset 0, the block-causal recompute pass, a second-block step at offset 4680."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd import _lib
+    lib = _lib.load()
+    cfg, text_dim, tiny_inputs = _tiny()
+    w = wo.make_weights(cfg, seed=0, text_dim=text_dim)
+    lat, ctx = tiny_inputs()
+    t = torch.ones([1, 3], dtype=torch.int64) * 700
+    t0 = torch.zeros([1, 3], dtype=torch.int64)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.rtv_dit_set_direct_v(mode)
+            model, wr = _build(cfg, text_dim, w)
+            kv, ca = _caches(cfg, 9360)
+            for c in kv:                      # poison: a row the GEMM fails to write would show
+                c["v"].fill_(7.0)
+                c["k"].fill_(7.0)
+            cond = {"prompt_embeds": [ctx.to(DEV)]}
+            a, _ = wr(lat[0].to(DEV), cond, t.to(DEV), kv, ca, current_start=0)
+            for c in kv:
+                c["global_end_index"] = 0
+                c["local_end_index"] = 0
+            model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560,
+                                                                         num_frame_per_block=3)
+            rc, _ = wr(lat[2].to(DEV), cond, t0.to(DEV), kv, ca, current_start=4680)
+            model.block_mask = None
+            b, _ = wr(lat[3].to(DEV), cond, t.to(DEV), kv, ca, current_start=4680)
+            res[mode] = ([x.clone() for x in (a, rc, b)], [(c["k"].clone(), c["v"].clone()) for c in kv])
+    finally:
+        lib.rtv_dit_set_direct_v(1)
+    for x0, x1 in zip(res[0][0], res[1][0]):
+        assert torch.equal(x0, x1)
+    for (k0, v0), (k1, v1) in zip(res[0][1], res[1][1]):
+        assert torch.equal(k0, k1) and torch.equal(v0, v1)
+        assert not (v1[:, :9360] == 7.0).all()
+
+
 def test_fp8_forward_matches_fp8_oracle():
     """BASELINE config 5's weight path (release_server.py:179-182, torchao Float8DynamicActivationFloat8WeightConfig
     PerTensor over every nn.Linear): native enable_fp8() forward vs the oracle's restatement of the same arithmetic, on a
