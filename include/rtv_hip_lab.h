@@ -45,9 +45,10 @@ int rtv_attn_set_skip_idle(int on);
  * kernel sums a pixel's taps in another order (0.03-0.25 % of the fp16 outputs differ by one rounding).  Lab build: 4 / 5 =
  * timing-only forms of 2 (no DMA in the loop / no epilogue; garbage results). */
 int rtv_conv_set_halo(int on);
-/* Self-attention K / V cache write: 1 (default) = the V third of the fused QKV projection is written into the V cache by the GEMM's
- * epilogue whenever the call's cache rows are one physical range (the RoPE / cache kernel then moves a third less); 0 = the kernel
- * copies V from the projection output, the r04 form.  Same bits in the cache. */
+/* Self-attention K / V cache write: 1 (default) = the V third of the fused QKV projection runs as a GEMM launch of its own whose output
+ * matrix is the call's rows of the V cache, whenever those are one physical row range (the RoPE / cache kernel then moves a third
+ * less); 0 = one fused launch and the kernel copies V out of its output, the r04 form.  Same bits in the cache wherever neither form
+ * splits K (tile config 4; the default dispatch cuts K by a launch's tile count). */
 int rtv_dit_set_direct_v(int on);
 /* RMSNorm(q,k) + RoPE + cache-write kernel: -1 = by row count (default), 0 = one 256-thread workgroup per row, 1 = two waves per row.
  * Bit-identical: both forms sum a row's squares in ONE canonical order (four accumulators per lane column, combined, then the

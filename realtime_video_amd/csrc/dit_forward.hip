@@ -240,7 +240,9 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
     (void)wq;
     if (!c.cfg->use_fp8) {
       // r05: when this call's cache rows are ONE physical row range (always, unless a ring write wraps), the V third of the projection
-      // is written into the V cache by the GEMM's epilogue; the RoPE / cache kernel then moves a third less (rope_parts | 4)
+      // is a GEMM of its own whose output matrix IS those rows of the V cache; the RoPE / cache kernel then moves a third less
+      // (rope_parts | 4).  (One launch with a second output matrix was built first: three more kernel arguments, or one more epilogue
+      // instantiation, cost the ping-pong kernel 3-4 % on the ffn-in shape - more than the copy.)
       void* v_dst = nullptr;
       if (kv && !kv_send && g_direct_v.load(std::memory_order_relaxed) && st->kv_v[l] && !(st->kv_row_stride & 7)) {
         int r0 = st->cache_row0 + c.r0;
@@ -257,8 +259,13 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
         if (one_range && !((uintptr_t)dst & 15)) v_dst = dst;
       }
       if (v_dst) {
-        RTV_TRY(gemm_two_outputs(b.xn, d, wp, d, b.qkv + n0, 3 * d, v_dst, (int)st->kv_row_stride, 2 * d - n0, c.rc, nn, d, bq + n0, 0, nullptr,
-                                 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc, c.stream));
+        // two launches: columns [n0, 2d) into the projection buffer, the V third straight into the cache rows (Q | K at M = 4680 is 760
+        // tiles = 2.97 rounds of the 256 CUs, V the o-projection's shape: +6 us on the fused launch's 563, against the 21 us the copy cost)
+        if (2 * d > n0)
+          RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, 2 * d - n0, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16,
+                           c.tc, c.stream));
+        RTV_TRY(rtv_gemm(b.xn, d, (const char*)lw.qkv_w + (size_t)2 * d * d * welt, d, v_dst, (int)st->kv_row_stride, c.rc, d, d, bq + 2 * d,
+                         0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc, c.stream));
         v_in_place = true;
       } else {
         RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, nn, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc,

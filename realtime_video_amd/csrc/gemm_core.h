@@ -31,10 +31,6 @@ struct GemmParams {
   const uint16_t* residual;  // [M][ldr] or null (may alias C)
   int ldr;
   int tiles_m, tiles_n;
-  // r05: output columns n >= n2 go to a second matrix, C2[m][n - n2] (row stride ldc2; n2 a multiple of 8; no residual) - the V third
-  // of the fused QKV projection lands in the KV cache directly instead of being copied there by the RoPE / cache kernel
-  uint16_t* C2 = nullptr;
-  int ldc2 = 0, n2 = 0;
 };
 
 template <bool F16>
@@ -162,8 +158,7 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int m, int n,
   u32x2 o;
   o[0] = (uint32_t)T::from_f32(v[0]) | ((uint32_t)T::from_f32(v[1]) << 16);
   o[1] = (uint32_t)T::from_f32(v[2]) | ((uint32_t)T::from_f32(v[3]) << 16);
-  uint16_t* dst = (p.C2 && n >= p.n2) ? p.C2 + (size_t)m * p.ldc2 + (n - p.n2) : p.C + (size_t)m * p.ldc + n;
-  *(u32x2*)dst = o;
+  *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
 }
 
 template <bool F16, typename Cfg>
@@ -281,10 +276,7 @@ __device__ __forceinline__ void store_tile_lds_impl(const GemmParams& p, int m_b
       for (int i = 0; i < 4; ++i)
         t[i] = T::pack2(T::lo_f32(t[i]) + T::lo_f32(res[ps][i]), T::hi_f32(t[i]) + T::hi_f32(res[ps][i]));
     }
-    if (m < p.M && n_ok) {
-      uint16_t* dst = (p.C2 && n >= p.n2) ? p.C2 + (size_t)m * p.ldc2 + (n - p.n2) : p.C + (size_t)m * p.ldc + n;
-      *(u32x4*)dst = t;
-    }
+    if (m < p.M && n_ok) *(u32x4*)(p.C + (size_t)m * p.ldc + n) = t;
   }
 }
 

@@ -48,9 +48,6 @@ int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, i
                     hipStream_t stream);
 
 // elementwise.hip: rtv_qk_norm_rope_cache with the optional head-group scatter, and its inverse for the attention output
-int gemm_two_outputs(const void* A, int lda, const void* W, int ldw, void* C, int ldc, void* C2, int ldc2, int n2, int M, int N, int K,
-                     const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame, int row_offset,
-                     const void* residual, int ldr, int dtype, int tile_cfg, rtv_stream_t stream);   // runtime.hip
 int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
                         int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
                         const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,

@@ -197,20 +197,7 @@ int rtv_prof_read(int cls, double* total_ms, int64_t* launches, double* total_wo
 int rtv_gemm(const void* A, int lda, const void* W, int ldw, void* C, int ldc, int M, int N, int K,
              const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame, int row_offset,
              const void* residual, int ldr, int dtype, int tile_cfg, rtv_stream_t stream) {
-  return rtv::gemm_two_outputs(A, lda, W, ldw, C, ldc, nullptr, 0, 0, M, N, K, bias, act, gate, gate_stride, rows_per_frame, row_offset,
-                               residual, ldr, dtype, tile_cfg, stream);
-}
-
-}  // extern "C"
-
-namespace rtv {
-// rtv_gemm with output columns n >= n2 written to C2[m][n - n2] (C2 == null: plain rtv_gemm).  Internal (dit_forward.hip).
-int gemm_two_outputs(const void* A, int lda, const void* W, int ldw, void* C, int ldc, void* C2, int ldc2, int n2, int M, int N, int K,
-                     const void* bias, int act, const void* gate, int gate_stride, int rows_per_frame, int row_offset,
-                     const void* residual, int ldr, int dtype, int tile_cfg, rtv_stream_t stream) {
   if (!A || !W || !C) return set_error(-1, "gemm: null operand");
-  if (C2 && (residual || (n2 & 7) || n2 <= 0 || n2 >= N || (ldc2 & 7) || ((uintptr_t)C2 & 15)))
-    return set_error(-1, "gemm: second output needs n2 a multiple of 8 inside (0, N), a 16-byte aligned base and stride, no residual");
   if (((uintptr_t)A | (uintptr_t)W) & 15) return set_error(-1, "gemm: A/W must be 16-byte aligned");
   if (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)gate | (uintptr_t)residual) & 7)
     return set_error(-1, "gemm: C/bias/gate/residual must be 8-byte aligned");
@@ -235,12 +222,7 @@ int gemm_two_outputs(const void* A, int lda, const void* W, int ldw, void* C, in
   p.residual = (const uint16_t*)residual;
   p.ldr = ldr;
   p.tiles_m = p.tiles_n = 0;
-  p.C2 = (uint16_t*)C2;
-  p.ldc2 = ldc2;
-  p.n2 = n2;
   return launch_gemm(p, dtype, tile_cfg, (hipStream_t)stream);
 }
-}  // namespace rtv
 
-extern "C" {
 }  // extern "C"

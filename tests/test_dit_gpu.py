@@ -355,7 +355,9 @@ def test_context_parallel_phase_api_equals_unsharded(world, exchange, heads):
     around self-attention - "rows": K/V all-gather into a replicated cache; "heads": the all-to-all pair of
     rtv_dit_layer_{qkv,attn,rest}_hp, every rank attending all rows for its own heads.  All shards run in lockstep on
     this one GPU and must reproduce the unsharded forward bit for bit - denoise pass at a non-zero cache offset and the
-    block-causal recompute pass."""
+    block-causal recompute pass.  Tile config 4 (no split-K): the default dispatch cuts K by a launch's tile count, i.e. by the
+    shard's row count and by which projections share a launch (r05: the unsharded forward runs the V projection as a launch of its own,
+    straight into the cache), and a K-split tile sums its halves in another order (profiles/r04_gemm_shard_identity.log)."""
     from oracle import wan_oracle as wo
     from realtime_video_amd.parallel import SimulatedContextParallel
     cfg, text_dim, tiny_inputs = _tiny()
@@ -367,6 +369,7 @@ def test_context_parallel_phase_api_equals_unsharded(world, exchange, heads):
     for cp in (None, SimulatedContextParallel(world, exchange)):
         model, wr = _build(cfg, text_dim, w)
         model.context_parallel = cp
+        model.gemm_tile_cfg = 4
         assert model.kv_cache_heads() == heads          # a simulation shares one full-head cache
         kv, ca = _caches(cfg, 9360)
         t = torch.ones([1, 3], dtype=torch.int64, device=DEV) * 700
@@ -398,6 +401,7 @@ def test_context_parallel_kv_split_attention_within_tolerance(world, exchange, h
     for cp in (None, SimulatedContextParallel(world, exchange, attn_kv_splits=splits)):
         model, wr = _build(cfg, text_dim, w)
         model.context_parallel = cp
+        model.gemm_tile_cfg = 4     # shard-invariant GEMMs (see test_context_parallel_phase_api_equals_unsharded): layer 0's K is compared bitwise
         kv, ca = _caches(cfg, 9360)
         t = torch.ones([1, 3], dtype=torch.int64, device=DEV) * 700
         model.block_mask = model._prepare_blockwise_causal_attn_mask(device=DEV, num_frames=3, frame_seqlen=1560,
