@@ -238,34 +238,35 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
   {
     const void* wp = (const char*)lw.qkv_w + (size_t)n0 * d * welt;
     (void)wq;
-    if (!c.cfg->use_fp8) {
-      // r05: when this call's cache rows are ONE physical row range (always, unless a ring write wraps), the V third of the projection
-      // is a GEMM of its own whose output matrix IS those rows of the V cache; the RoPE / cache kernel then moves a third less
-      // (rope_parts | 4).  (One launch with a second output matrix was built first: three more kernel arguments, or one more epilogue
-      // instantiation, cost the ping-pong kernel 3-4 % on the ffn-in shape - more than the copy.)
-      void* v_dst = nullptr;
-      if (kv && !kv_send && g_direct_v.load(std::memory_order_relaxed) && st->kv_v[l] && !(st->kv_row_stride & 7)) {
-        int r0 = st->cache_row0 + c.r0;
-        const int S = st->ring_lo, R = st->ring_size;
-        bool one_range = true;
-        if (R > 0 && r0 + c.rc > S) {
-          if (r0 < S) one_range = false;                          // sink rows and ring rows in one call
-          else {
-            r0 = S + (r0 - S + st->ring_shift) % R;
-            one_range = r0 + c.rc <= S + R;
-          }
+    // r05: when this call's cache rows are ONE physical row range (always, unless a ring write wraps), the V third of the projection
+    // is a GEMM of its own whose output matrix IS those rows of the V cache; the RoPE / cache kernel then moves a third less
+    // (rope_parts | 4).  (One launch with a second output matrix was built first: three more kernel arguments, or one more epilogue
+    // instantiation, cost the ping-pong kernel 3-4 % on the ffn-in shape - more than the copy.)
+    void* v_dst = nullptr;
+    if (kv && !kv_send && g_direct_v.load(std::memory_order_relaxed) && st->kv_v[l] && !(st->kv_row_stride & 7)) {
+      int r0 = st->cache_row0 + c.r0;
+      const int S = st->ring_lo, R = st->ring_size;
+      bool one_range = true;
+      if (R > 0 && r0 + c.rc > S) {
+        if (r0 < S) one_range = false;                          // sink rows and ring rows in one call
+        else {
+          r0 = S + (r0 - S + st->ring_shift) % R;
+          one_range = r0 + c.rc <= S + R;
         }
-        uint16_t* dst = (uint16_t*)st->kv_v[l] + (size_t)r0 * st->kv_row_stride;
-        if (one_range && !((uintptr_t)dst & 15)) v_dst = dst;
       }
+      uint16_t* dst = (uint16_t*)st->kv_v[l] + (size_t)r0 * st->kv_row_stride;
+      if (one_range && !((uintptr_t)dst & 15)) v_dst = dst;
+    }
+    const void* wv = (const char*)lw.qkv_w + (size_t)2 * d * d * welt;   // the V rows of the fused weight
+    if (!c.cfg->use_fp8) {
       if (v_dst) {
         // two launches: columns [n0, 2d) into the projection buffer, the V third straight into the cache rows (Q | K at M = 4680 is 760
         // tiles = 2.97 rounds of the 256 CUs, V the o-projection's shape: +6 us on the fused launch's 563, against the 21 us the copy cost)
         if (2 * d > n0)
           RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, 2 * d - n0, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16,
                            c.tc, c.stream));
-        RTV_TRY(rtv_gemm(b.xn, d, (const char*)lw.qkv_w + (size_t)2 * d * d * welt, d, v_dst, (int)st->kv_row_stride, c.rc, d, d, bq + 2 * d,
-                         0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc, c.stream));
+        RTV_TRY(rtv_gemm(b.xn, d, wv, d, v_dst, (int)st->kv_row_stride, c.rc, d, d, bq + 2 * d, 0, nullptr, 0, 0, 0, nullptr, 0,
+                         RTV_DTYPE_BF16, c.tc, c.stream));
         v_in_place = true;
       } else {
         RTV_TRY(rtv_gemm(b.xn, d, wp, d, b.qkv + n0, 3 * d, c.rc, nn, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, RTV_DTYPE_BF16, c.tc,
@@ -274,8 +275,17 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
     } else {
       if (!c.w->fp8_scales) return set_error(-1, "dit: use_fp8 needs rtv_dit_weights.fp8_scales");
       if (rtv_quantize_fp8(b.xn, d, c.rc, d, b.q8, d, b.fscale, b.fscale + 1, c.stream)) return -1;
-      RTV_TRY(rtv_gemm_fp8(b.q8, d, wp, d, b.fscale, c.w->fp8_scales[S_LAYER0 + S_PER_LAYER * l + S_QKV], b.qkv + n0, 3 * d, c.rc, nn, d,
-                           bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, c.stream));
+      const float ws = c.w->fp8_scales[S_LAYER0 + S_PER_LAYER * l + S_QKV];   // ONE scale for the fused weight, whichever rows a launch takes
+      if (v_dst) {
+        if (2 * d > n0)
+          RTV_TRY(rtv_gemm_fp8(b.q8, d, wp, d, b.fscale, ws, b.qkv + n0, 3 * d, c.rc, 2 * d - n0, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0,
+                               c.stream));
+        RTV_TRY(rtv_gemm_fp8(b.q8, d, wv, d, b.fscale, ws, v_dst, (int)st->kv_row_stride, c.rc, d, d, bq + 2 * d, 0, nullptr, 0, 0, 0, nullptr,
+                             0, c.stream));
+        v_in_place = true;
+      } else {
+        RTV_TRY(rtv_gemm_fp8(b.q8, d, wp, d, b.fscale, ws, b.qkv + n0, 3 * d, c.rc, nn, d, bq + n0, 0, nullptr, 0, 0, 0, nullptr, 0, c.stream));
+      }
     }
   }
   const int rope_parts = (q ? 1 : 0) | (kv ? 2 : 0) | (v_in_place ? 4 : 0);
