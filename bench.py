@@ -336,6 +336,7 @@ def main():
         sess.generate_block()
     barrier()
     ops.prof_reset()
+    ops.dispatch_counts(reset=True)      # the kernel variants that run inside the timed region go into config.kernel_variants
     strides = {k: int(v) for k, v in (kv.split("=") for kv in args.profile_stride.split(",") if kv)}
     for cls in ("gemm", "attn", "layernorm", "rope", "conv", "misc"):
         ops.prof_set_stride(cls, 1 if args.profile_classes == "all" else strides.get(cls, 1))
@@ -361,6 +362,7 @@ def main():
           f"of which {1e3 * wait_s[0] / args.steps:.1f} ms waiting for the previous block's frames -> "
           f"launch issue {1e3 * (host_issue_s - wait_s[0]) / args.steps:.1f} ms per block", file=sys.stderr)
     ops.prof_enable(False)
+    kernel_variants = ops.dispatch_counts()
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -451,6 +453,9 @@ def main():
             "event_bracket_overhead_us": 1e3 * bracket_ms,
             "kernel_ms_per_block_uncorrected": {k: v["ms_class_raw"] / args.steps for k, v in prof.items() if v["launches"] > 0},
             "max_memory_allocated_GB": peak_mem / 1e9,
+            # launches per kernel VARIANT inside the timed region (rtv_dispatch_counts; under --hipgraph the replayed launches are not
+            # counted: the dispatch ran at capture time): a shape falling back to an older kernel shows here
+            "kernel_variants": kernel_variants,
             "last_block_latents_checksum": latents_checksum,
         },
         "roofline": {

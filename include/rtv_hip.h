@@ -32,9 +32,9 @@ typedef void* rtv_stream_t; /* hipStream_t */
 
 /* ---- library ---------------------------------------------------------------------------- */
 /* ABI revision of this header: bumped whenever a struct layout or a signature below changes (101: rtv_dit_config gained the
- * trailing max_attn_kv_splits; 102: rtv_attn_set_waves value 3, r05).  A binding compares rtv_version() with the
+ * trailing max_attn_kv_splits; 102: rtv_attn_set_waves value 3, r05; 103: rtv_dispatch_* added, r06).  A binding compares rtv_version() with the
  * RTV_ABI_VERSION it was written against and refuses a mismatch (realtime_video_amd/_lib.py does). */
-#define RTV_ABI_VERSION 102
+#define RTV_ABI_VERSION 103
 int rtv_version(void);
 const char* rtv_last_error(void);
 
@@ -55,6 +55,14 @@ int rtv_prof_read_seen(int cls, int64_t* launches, double* work);
  * in ms.  A bracketed launch reads kernel time + this (the two markers are processed by the queue on either side of the dispatch);
  * bench.py subtracts it per bracketed launch from the class times.  Synchronises the stream. */
 int rtv_prof_bracket_overhead(int n, rtv_stream_t stream, double* avg_ms);
+
+/* Which kernel VARIANT the dispatch rules chose, counted per launch since load / the last reset (one relaxed atomic per launch):
+ * rtv_dispatch_counts fills counts[0 .. min(n, K)) and returns K, the number of variants; rtv_dispatch_name(i) is variant i's
+ * name ("gemm8_kernel<256x256 ping-pong>", "attn_fwd_w4_kernel<one wave per SIMD>", ...).  bench.py records the variants that ran
+ * in its JSON line, so that a shape silently falling back to an older kernel shows in the driver's numbers. */
+int rtv_dispatch_counts(int64_t* counts, int n);
+const char* rtv_dispatch_name(int id);
+int rtv_dispatch_reset(void);
 
 /* ---- K1/K2/K3: attention backend --------------------------------------------------------
  * Replaces wan/modules/attention.py:150-212 `attention(q,k,v,...)` (and the sage custom op

@@ -591,11 +591,41 @@ def golden_full_width():
         out["reference_forward_s"], out["port_forward_s"], out["threads"], out["port_vs_reference_rel_l2"]))
 
 
+def golden_loader_manifest(ref):
+    """tests/golden/checkpoint_manifest.json: the state-dict key / shape / dtype set a checkpoint for the reference's
+    `WanDiffusionWrapper(model_name=..., is_causal=True)` carries (release_server.py:160-167: `load_file(...)` -> keys prefixed
+    `model.` because the wrapper holds the CausalWanModel as `self.model`, utils/wan_wrapper.py:121-151), for both architectures the
+    server can load (:162-165), taken from the reference's OWN module tree instantiated on the meta device (no memory, no weights).
+    `from_pretrained` needs diffusers + a config.json, neither is here: the constructor is called with the dims of
+    wan/configs/wan_t2v_14B.py:21-25 / wan_t2v_1_3B.py:21-25.  Data only: names and shapes."""
+    import json
+    archs = {"Wan2.1-T2V-14B": dict(dim=5120, ffn_dim=13824, num_heads=40, num_layers=40),
+             "Wan2.1-T2V-1.3B": dict(dim=1536, ffn_dim=8960, num_heads=12, num_layers=30)}
+    out = {}
+    for name, a in archs.items():
+        with torch.device("meta"):
+            m = ref.cm.CausalWanModel(model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, freq_dim=256, text_dim=4096,
+                                      out_dim=16, qk_norm=True, cross_attn_norm=True, eps=1e-6, **a)
+        wrapper = torch.nn.Module()
+        wrapper.model = m                                   # the wrapper's only nn.Module child (utils/wan_wrapper.py:137-139)
+        sd = wrapper.state_dict()
+        out[name] = {"arch": a, "unfused": {k: list(v.shape) for k, v in sd.items()}}
+        for blk in m.blocks:                                # release_server.py:176-177
+            blk.self_attn.fuse_projections()
+        out[name]["fused"] = {k: list(v.shape) for k, v in wrapper.state_dict().items()}
+        print(name, len(out[name]["unfused"]), "keys unfused,", len(out[name]["fused"]), "fused,",
+              sum(int(torch.Size(v).numel()) for v in out[name]["unfused"].values()) / 1e9, "G parameters")
+    with open(os.path.join(OUT, "checkpoint_manifest.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     ref = ref_shim.load()
     which = sys.argv[1:] or ["ops", "dit", "rolling", "vae", "vae_single", "vae_enc", "vae_wrapper", "t5", "session", "webcam", "start_frame", "v2v", "pipeline"]
+    if "loader_manifest" in which:   # not in the default list (names / shapes only; does not change unless upstream's modules do)
+        golden_loader_manifest(ref)
     if "ops" in which:
         golden_ops(ref)
     if "dit" in which:

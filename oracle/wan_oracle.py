@@ -186,8 +186,11 @@ def fp8_linear(x, weight, bias, shards=1):
 
 
 def _fp8_shards(w, x):
+    """`rows`: the token-row count of the sharded forwards - an int, or a collection of them (a session's denoise forwards hold
+    4680 rows, its recompute forwards 4680 / 9360 / 14040 as the context grows)."""
     world, rows = w.get(FP8_ROW_SHARDS, (1, 0))
-    return world if x.dim() >= 2 and x.shape[-2] == rows else 1
+    rows = (rows,) if isinstance(rows, int) else tuple(rows)
+    return world if x.dim() >= 2 and x.shape[-2] in rows else 1
 
 
 def _linear(w, x, weight, bias):
@@ -570,19 +573,20 @@ def pipeline_inference(w, cfg, prompt_embeds, noise, initial_latent=None, denois
     if warp_denoising_step:                                                    # :29-32
         steps = torch.cat((scheduler.timesteps, torch.tensor([0], dtype=torch.float32)))[1000 - steps]
     n_heads, hd = cfg["num_heads"], cfg["dim"] // cfg["num_heads"]
-    kv = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype)
-    ca = initialize_crossattn_cache(cfg["num_layers"], 1, n_heads, hd, noise.dtype, cfg.get("text_len", 512))
+    dev = noise.device                      # the graph runs where its inputs live (host, or torch eager on a GPU)
+    kv = initialize_kv_cache(cfg["num_layers"], 1, kv_size, n_heads, hd, noise.dtype, dev)
+    ca = initialize_crossattn_cache(cfg["num_layers"], 1, n_heads, hd, noise.dtype, cfg.get("text_len", 512), dev)
     num_frames = noise.shape[1]
     n_in = initial_latent.shape[1] if initial_latent is not None else 0
     if not independent_first_frame or initial_latent is not None:
         num_blocks = num_frames // nfpb
     else:
         num_blocks = (num_frames - 1) // nfpb
-    output = torch.zeros([1, num_frames + n_in] + list(noise.shape[2:]), dtype=noise.dtype)
+    output = torch.zeros([1, num_frames + n_in] + list(noise.shape[2:]), dtype=noise.dtype, device=dev)
     start = 0
 
     def fwd(x, t):
-        return wrapper_forward(w, cfg, scheduler, x, prompt_embeds, t, kv, ca, start * FRAME_SEQLEN, attn_fn=attn_fn)
+        return wrapper_forward(w, cfg, scheduler, x, prompt_embeds, t.to(dev), kv, ca, start * FRAME_SEQLEN, attn_fn=attn_fn)
 
     if initial_latent is not None:                                             # Step 2, :136-168
         chunks = [1] if independent_first_frame else []

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RTV_LIB_PATH") or os.path.join(_HERE, "librtv_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 102   # include/rtv_hip.h RTV_ABI_VERSION this binding's structs / signatures mirror
+ABI_VERSION = 103   # include/rtv_hip.h RTV_ABI_VERSION this binding's structs / signatures mirror
 
 _lib = None
 

@@ -908,6 +908,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
     if (int st = check_launch("attn_fwd")) return st;
     const int64_t nrows = (int64_t)B * H * Lq;
     const dim3 cg((unsigned)((nrows + 15) / 16)), ct(256);
+    note_kernel(DK_ATTN_SPLIT_COMBINE);
     if (f16) hipLaunchKernelGGL((attn_combine_kernel<true>), cg, ct, 0, (hipStream_t)stream, p.part_o, p.part_ml, p.o, kv_splits, B, H, Lq, p.o_bs, p.o_rs);
     else hipLaunchKernelGGL((attn_combine_kernel<false>), cg, ct, 0, (hipStream_t)stream, p.part_o, p.part_ml, p.o, kv_splits, B, H, Lq, p.o_bs, p.o_rs);
     return check_launch("attn_combine");
@@ -930,6 +931,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   if (w4v == -2) w4v = Lkv >= 1024 ? W4_DEFAULT : -1;
   if (waves == 8 && w4v >= 0 && !f16 && Lkv1 == 0 && dup_key < 0 && offsets_fit) {
     if (int st = launch_attn_w4(p, f16, w4v, g, (hipStream_t)stream)) return st;
+    note_kernel(DK_ATTN_W4);
     if (kv_splits > 1) return combine();
     return check_launch("attn_w4");
   }
@@ -946,11 +948,13 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
     static LdsAttr pp_attr[2];
     const void* kp = f16 ? (const void*)attn_fwd_pp_kernel<true> : (const void*)attn_fwd_pp_kernel<false>;
     if (int st = ensure_dynamic_lds(kp, lds_pp, &pp_attr[f16], "attn_fwd")) return st;
+    note_kernel(DK_ATTN_FOUR_PHASE);
     if (f16) hipLaunchKernelGGL((attn_fwd_pp_kernel<true>), g, t, lds_pp, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_pp_kernel<false>), g, t, lds_pp, (hipStream_t)stream, p);
     if (kv_splits > 1) return combine();
     return check_launch("attn_fwd");
   }
+  note_kernel(waves == 4 ? DK_ATTN_LOCKSTEP_128ROW : DK_ATTN_LOCKSTEP_256ROW);
   if (waves == 4) {
     if (f16) hipLaunchKernelGGL((attn_fwd_kernel<true, 4>), g, t, lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_fwd_kernel<false, 4>), g, t, lds, (hipStream_t)stream, p);

@@ -258,6 +258,21 @@ static int dit_layer_proj(Ctx& c, int l, int parts, int world, void* q_send, voi
       if (one_range && !((uintptr_t)dst & 15)) v_dst = dst;
     }
     const void* wv = (const char*)lw.qkv_w + (size_t)2 * d * d * welt;   // the V rows of the fused weight
+    // Everything the RoPE / cache launch behind the GEMMs would refuse is refused HERE, before a GEMM has written V rows into the
+    // cache (a failing call used to leave the V rows overwritten and the K rows untouched).
+    {
+      const int rp = (q ? 1 : 0) | (kv ? 2 : 0) | (v_dst ? 4 : 0);
+      if (q_send || kv_send) {
+        RTV_TRY(hp_check(c, world));
+        const int gc = d / world;
+        if ((q && !q_send) || (kv && !kv_send)) return set_error(-1, "dit: exchange buffers required");
+        RTV_TRY(qk_norm_rope_check(2 * gc, 0, c.rc, d, c.H, c.F, c.gh, c.gw, st->start_frame, c.r0, gc, (int64_t)c.rc * gc,
+                                   (int64_t)c.rc * 2 * gc, 0, 0, 0, rp));
+      } else {
+        RTV_TRY(qk_norm_rope_check(st->kv_row_stride, st->cache_row0, c.rc, d, c.H, c.F, c.gh, c.gw, st->start_frame, c.r0, 0, 0, 0,
+                                   st->ring_lo, st->ring_size, st->ring_shift, rp));
+      }
+    }
     if (!c.cfg->use_fp8) {
       if (v_dst) {
         // two launches: columns [n0, 2d) into the projection buffer, the V third straight into the cache rows (Q | K at M = 4680 is 760

@@ -489,11 +489,12 @@ __global__ void unpatchify_kernel(const bf16_t* __restrict__ rows, bf16_t* __res
 
 namespace rtv {
 // Shared launcher; group_cols == 0 is the plain cache write of the C entry below.
-int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
-                        int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
-                        const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
-                        int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
-                        int parts, rtv_stream_t stream) {
+// Argument validation of the launcher below, callable by itself: the DiT sequencer checks a call's ring / row range / exchange
+// geometry BEFORE it launches the projection GEMMs whose output the RoPE / cache kernel consumes (the V third of the projection
+// writes cache rows directly: a call that is going to be refused must not have touched the cache).
+int qk_norm_rope_check(int64_t cache_row_stride, int cache_row0, int M, int d, int num_heads, int F, int gh, int gw, int start_frame,
+                       int row_offset, int group_cols, int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size,
+                       int ring_shift, int parts) {
   if (M <= 0) return 0;
   if (parts < 1 || parts > 7 || parts == 4 || parts == 5) return set_error(-1, "qk_norm_rope_cache: parts must be 1 (q), 2 (k, v) or 3 (+ 4: V in place)");
   if (ring_size < 0 || ring_lo < 0 || ring_shift < 0 || (ring_size > 0 && ring_shift >= ring_size))
@@ -510,6 +511,19 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
   if (cache_row0 < 0) return set_error(-1, "qk_norm_rope_cache: negative cache row");
   if (group_cols && (group_cols % hd || d % group_cols || q_group_stride % 8 || kv_group_stride % 8))
     return set_error(-1, "qk_norm_rope_cache: head groups must be whole heads dividing d");
+  return 0;
+}
+
+int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
+                        int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
+                        const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,
+                        int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size, int ring_shift,
+                        int parts, rtv_stream_t stream) {
+  if (M <= 0) return 0;
+  if (qk_norm_rope_check(cache_row_stride, cache_row0, M, d, num_heads, F, gh, gw, start_frame, row_offset, group_cols, q_group_stride,
+                         kv_group_stride, ring_lo, ring_size, ring_shift, parts))
+    return -1;
+  const int hd = d / num_heads;
   RopeArgs a;
   a.qkv = (const bf16_t*)qkv;
   a.q_out = (bf16_t*)q_out;

@@ -102,6 +102,7 @@ static int launch_cfg(GemmParams p, hipStream_t stream) {
   const int lds = 2 * Cfg::STAGE_BYTES;
   if (int st = ensure_dynamic_lds((const void*)kern, lds, &lds_attr, "gemm")) return st;
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);  // fp16 GEMMs belong to the VAE
+  note_kernel(BM == 128 && BN == 128 ? DK_GEMM_128x128 : DK_GEMM_OTHER_CFG);
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
   return check_launch("gemm");
 }
@@ -137,8 +138,13 @@ int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream
     // at least 4/5 of a round run on the one-wave-per-SIMD kernel (gemm5.hip): one round of EQUAL units instead of an under-filled
     // round of 256-row tiles or 1.17 rounds of 128-row ones - QKV 111 -> 83 us, ffn-in 93 -> 74 at 585 rows, 183 -> 154 / 180 -> 143
     // at 1170 (hipBLASLt: 95 / 79 / 179 / 236; profiles/r05_gemm5_cp_shapes.log).  Unsplit there: the K order of tile config 4.
-    const long tiles160 = ((p.M + 159) / 160) * tiles_n;
-    if (!f16 && p.K >= 1024 && p.M <= 1280 && tiles160 * 5 >= G * 4) return launch_gemm5(p, f16, true, stream);
+    // Only where 160-row tiles multiply no more rows than the 256-row kernel would (585 -> 640 = 640, 1170 -> 1280 = 1280; but
+    // 512 -> 640 > 512 and 1024 -> 1120 > 1024: row counts that tile exactly by 256 stay on the ping-pong kernels - the text
+    // encoder's 512 x 20480 x 4096 would otherwise run 320 padded tiles = 1.25 rounds instead of 160 exact ones) and where a
+    // second round, if any, is at least a quarter full (the rule ignored padding and round count).
+    const long rt160 = (p.M + 159) / 160, tiles160 = rt160 * tiles_n, tail160 = tiles160 % G;
+    const bool fill160 = tiles160 * 5 >= G * 4 && (tiles160 <= G || tail160 == 0 || tail160 * 4 >= G);
+    if (!f16 && p.K >= 1024 && p.M <= 1280 && rt160 * 160 <= eff256 && fill160) return launch_gemm5(p, f16, true, stream);
     if (!f16 && p.K >= 1024 && tiles128 >= 96 && (pad128 * 100 < eff256 * 93 || tiles256 * 8 < G * 5 || small_tail))
       return launch_gemm8m(p, f16, true, stream);
     // (deep-K problems with 64..127 tiles - ffn2 on a context-parallel token shard - also win: every tile is then split

@@ -249,6 +249,7 @@ int launch_gemm5(const GemmParams& p_, bool f16, bool split_k, hipStream_t strea
   const void* kern = f16 ? (const void*)gemm5_kernel<true> : (const void*)gemm5_kernel<false>;
   if (int st = ensure_dynamic_lds(kern, g5::LDS_BYTES, &lds_attr[f16], "gemm5")) return st;
   ProfScope prof(f16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  note_kernel(DK_GEMM5_160x256);
   if (f16) hipLaunchKernelGGL(gemm5_kernel<true>, dim3(grid), dim3(g5::THREADS), g5::LDS_BYTES, stream, p, sp);
   else hipLaunchKernelGGL(gemm5_kernel<false>, dim3(grid), dim3(g5::THREADS), g5::LDS_BYTES, stream, p, sp);
   return check_launch("gemm5");

@@ -696,6 +696,7 @@ static int launch_gemm8_t(GemmParams p, bool allow_split, hipStream_t stream) {
     grid += pair_pad;
   }
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  note_kernel(DK_GEMM8_256x256);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8::LDS_BYTES, stream, p, sp);
   return check_launch("gemm8");
 }
@@ -711,6 +712,7 @@ static int launch_gemm8m_t(GemmParams p, bool allow_split, hipStream_t stream) {
   int grid = 0;
   if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / g8m::BK, allow_split, &sp, &grid, stream)) return st;
   ProfScope prof(F16 ? PROF_CONV : PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  note_kernel(DK_GEMM8M_128x256);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(g8::THREADS), g8m::LDS_BYTES, stream, p, sp);
   return check_launch("gemm8m");
 }

@@ -328,6 +328,7 @@ int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, i
   if (int st = plan_split_k(p.tiles_m * p.tiles_n, p.K / gf8::BK, true, &sp, &grid, stream)) return st;
   gf8::Fp8Args f{A, W, lda, ldw, a_scale, w_scale};
   ProfScope prof(PROF_GEMM, stream, 2.0 * p.M * (double)p.N * p.K);
+  note_kernel(DK_GEMM_FP8_256x256);
   hipLaunchKernelGGL(gemm_fp8_kernel, dim3(grid), dim3(gf8::THREADS), gf8::LDS_BYTES, stream, p, f, sp);
   return check_launch("gemm_fp8");
 }

@@ -35,6 +35,16 @@ struct ProfScope {
   hipStream_t stream;
 };
 
+// Which kernel VARIANT a dispatch rule chose, counted per launch (rtv_dispatch_counts): bench.py records the variants that ran in
+// its JSON line, so that a dispatch regression - a shape silently falling back to an older kernel - shows in the driver's numbers
+// (VERDICT r05 item 8).  One relaxed atomic increment per launch.
+enum DispatchKernel {
+  DK_GEMM_128x128 = 0, DK_GEMM_OTHER_CFG, DK_GEMM8_256x256, DK_GEMM8M_128x256, DK_GEMM5_160x256, DK_GEMM_FP8_256x256,
+  DK_ATTN_W4, DK_ATTN_FOUR_PHASE, DK_ATTN_LOCKSTEP_256ROW, DK_ATTN_LOCKSTEP_128ROW, DK_ATTN_SPLIT_COMBINE,
+  DK_CONV_HALO4P, DK_CONV_HALO4, DK_CONV_HALO, DK_CONV_IGEMM, DK_COUNT
+};
+void note_kernel(int id);
+
 struct GemmParams;
 int launch_gemm(const GemmParams& p, int dtype, int tile_cfg, hipStream_t stream);
 int launch_gemm8(const GemmParams& p, bool f16, bool split_k, hipStream_t stream);  // 256x256 ping-pong kernel (gemm8.hip)
@@ -48,6 +58,9 @@ int launch_gemm_fp8(GemmParams p, const uint8_t* A, int lda, const uint8_t* W, i
                     hipStream_t stream);
 
 // elementwise.hip: rtv_qk_norm_rope_cache with the optional head-group scatter, and its inverse for the attention output
+int qk_norm_rope_check(int64_t cache_row_stride, int cache_row0, int M, int d, int num_heads, int F, int gh, int gw, int start_frame,
+                       int row_offset, int group_cols, int64_t q_group_stride, int64_t kv_group_stride, int ring_lo, int ring_size,
+                       int ring_shift, int parts);
 int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cache, int64_t cache_row_stride,
                         int cache_row0, int M, int d, int num_heads, float eps, const void* wq, const void* wk,
                         const void* rope_cs, int F, int gh, int gw, int start_frame, int row_offset, int group_cols,

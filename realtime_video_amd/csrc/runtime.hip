@@ -44,6 +44,17 @@ int device_num_cus() {
   return n;
 }
 
+static std::atomic<int64_t> g_dispatch[DK_COUNT];
+static const char* const g_dispatch_names[DK_COUNT] = {
+    "gemm_kernel<128x128>", "gemm_kernel<other tile config>", "gemm8_kernel<256x256 ping-pong>", "gemm8m_kernel<128x256 ping-pong>",
+    "gemm5_kernel<160x256 one wave per SIMD>", "gemm_fp8_kernel<256x256>",
+    "attn_fwd_w4_kernel<one wave per SIMD>", "attn_fwd_pp_kernel<four-phase>", "attn_fwd_kernel<lockstep, 256 rows>",
+    "attn_fwd_kernel<lockstep, 128 rows>", "attn_combine_kernel<kv split>",
+    "conv_halo4p_kernel<persistent>", "conv_halo4_kernel", "conv_halo_kernel", "conv_igemm_kernel"};
+void note_kernel(int id) {
+  if (id >= 0 && id < DK_COUNT) g_dispatch[id].fetch_add(1, std::memory_order_relaxed);
+}
+
 int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error((int)e, what);
@@ -116,6 +127,18 @@ int rtv_lab_build(void) {
 #endif
 }
 
+int rtv_dispatch_counts(int64_t* counts, int n) {
+  for (int i = 0; counts && i < n && i < DK_COUNT; ++i) counts[i] = g_dispatch[i].load(std::memory_order_relaxed);
+  return DK_COUNT;
+}
+
+const char* rtv_dispatch_name(int id) { return id >= 0 && id < DK_COUNT ? g_dispatch_names[id] : ""; }
+
+int rtv_dispatch_reset(void) {
+  for (auto& c : g_dispatch) c.store(0, std::memory_order_relaxed);
+  return 0;
+}
+
 int rtv_prof_enable(int class_mask) {
   g_prof_mask = (unsigned)class_mask;
   return 0;
@@ -145,19 +168,27 @@ int rtv_prof_set_stride(int cls, int stride) {
 int rtv_prof_bracket_overhead(int n, rtv_stream_t stream_, double* avg_ms) {
   if (n < 1 || n > 4096 || !avg_ms) return set_error(-1, "prof_bracket_overhead: 1 <= n <= 4096, avg_ms != null");
   hipStream_t stream = (hipStream_t)stream_;
-  std::vector<hipEvent_t> ev(2 * (size_t)n);
-  for (auto& e : ev)
-    if (hipEventCreate(&e) != hipSuccess) return set_error(-1, "prof_bracket_overhead: hipEventCreate");
+  std::vector<hipEvent_t> ev;
+  ev.reserve(2 * (size_t)n);
+  // every error return destroys the events created so far (they leaked)
+  auto fail = [&](const char* what) {
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return set_error(-1, what);
+  };
+  for (int i = 0; i < 2 * n; ++i) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return fail("prof_bracket_overhead: hipEventCreate");
+    ev.push_back(e);
+  }
   for (int i = 0; i < n; ++i) {
     if (hipEventRecord(ev[2 * i], stream) != hipSuccess || hipEventRecord(ev[2 * i + 1], stream) != hipSuccess)
-      return set_error(-1, "prof_bracket_overhead: hipEventRecord");
+      return fail("prof_bracket_overhead: hipEventRecord");
   }
-  if (hipStreamSynchronize(stream) != hipSuccess) return set_error(-1, "prof_bracket_overhead: hipStreamSynchronize");
+  if (hipStreamSynchronize(stream) != hipSuccess) return fail("prof_bracket_overhead: hipStreamSynchronize");
   double tot = 0;
   for (int i = 0; i < n; ++i) {
     float t = 0;
-    if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) != hipSuccess)
-      return set_error(-1, "prof_bracket_overhead: hipEventElapsedTime");
+    if (hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]) != hipSuccess) return fail("prof_bracket_overhead: hipEventElapsedTime");
     tot += t;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);

@@ -1308,6 +1308,7 @@ static int launch_conv_halo(ConvParams p, hipStream_t stream, int form) {   // f
   if (int st = ensure_dynamic_lds(kern, lds, &lds_attr[form], "conv")) return st;
   ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * 9 * p.kt * p.Cin);
   const dim3 grid(p.T * tiles_y * tiles_x * (p.Cout / 96));
+  note_kernel(form == 4 ? DK_CONV_HALO4P : form == 0 ? DK_CONV_HALO : DK_CONV_HALO4);
   if (form == 4) {   // one workgroup per CU, rounded down to whole XCD rows so that a virtual id keeps its XCD (id % 8)
     const int cus = device_num_cus() > 0 ? device_num_cus() : 256;
     const int nwg = (int)grid.x < cus ? (int)grid.x : cus / 8 * 8;
@@ -1334,6 +1335,7 @@ static int launch_conv_cfg(ConvParams p, hipStream_t stream) {
   static LdsAttr lds_attr;   // per device (a second GPU used from this process needs the attribute as well)
   if (int st = ensure_dynamic_lds((const void*)kern, lds, &lds_attr, "conv")) return st;
   ProfScope prof(PROF_CONV, stream, 2.0 * p.M * (double)p.Cout * p.kt * p.kh * p.kw * p.Cin);
+  note_kernel(DK_CONV_IGEMM);
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(Cfg::NT), lds, stream, p);
   return check_launch("conv");
 }

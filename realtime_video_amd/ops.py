@@ -64,6 +64,22 @@ def prof_bracket_overhead(n=256):
     return ms.value
 
 
+def dispatch_counts(reset=False):
+    """{kernel variant name: launches since load / the last reset} for the variants that ran (rtv_dispatch_counts): which GEMM /
+    attention / conv kernels the dispatch rules actually chose."""
+    lib = _lib.load()
+    lib.rtv_dispatch_counts.restype, lib.rtv_dispatch_counts.argtypes = ctypes.c_int, [ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    lib.rtv_dispatch_name.restype, lib.rtv_dispatch_name.argtypes = ctypes.c_char_p, [ctypes.c_int]
+    n = lib.rtv_dispatch_counts(None, 0)
+    buf = (ctypes.c_int64 * n)()
+    lib.rtv_dispatch_counts(buf, n)
+    out = {lib.rtv_dispatch_name(i).decode(): int(buf[i]) for i in range(n) if buf[i]}
+    if reset:
+        lib.rtv_dispatch_reset.restype, lib.rtv_dispatch_reset.argtypes = ctypes.c_int, []
+        lib.rtv_dispatch_reset()
+    return out
+
+
 def prof_read(cls):
     """-> ms / launches / work of the BRACKETED launches, seen_launches / seen_work of all launches of the class, and `ms_class` =
     the bracketed time scaled to the whole class by work."""

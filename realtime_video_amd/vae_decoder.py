@@ -300,17 +300,27 @@ class VAEDecoderWrapperSingle(VAEDecoderWrapper):
 
     NUM_CACHES = 32
 
+    _SHAPES = [(16, 1)] + [(384, 1)] * 11 + [(192, 2)] + [(384, 2)] * 6 + [(192, 4)] * 6 + [(96, 8)] * 7
+
     def zero_cache(self, h, w, dtype=torch.float16):
-        """The 32 zero caches of a new stream (demo_utils/constant.py:6-39 at latent size h x w).  In fp16 - what the decoder runs
-        in - they are handed out as views of a fresh, registered arena: the first forward() then finds its arena by lookup and
-        neither allocates nor copies 32 slots of zeros into a new one.  Other dtypes: plain tensors (copied in)."""
-        shapes = [(16, 1)] + [(384, 1)] * 11 + [(192, 2)] + [(384, 2)] * 6 + [(192, 4)] * 6 + [(96, 8)] * 7
-        if dtype == torch.float16 and self.row_range(h) == (0, 8 * h):
-            arena = self._new_arena(h, w)                      # zero-filled
-            views = self._cache_views(arena, (-arena.data_ptr()) % 256, h, w)[:self.NUM_CACHES]
-            assert [tuple(v.shape) for v in views] == [(1, c, 2, h * k, w * k) for c, k in shapes]
-            return views
-        return [torch.zeros(1, c, 2, h * k, w * k, dtype=dtype, device=self.device) for c, k in shapes]
+        """The 32 zero caches of a new stream (demo_utils/constant.py:6-39 at latent size h x w) as PLAIN tensors that stay zero:
+        the reference keeps them as a reusable constant (`feat_cache = ZERO_VAE_CACHE` for every new stream,
+        demo_utils/vae_torch2trt.py:168), so the same list may start any number of streams - the first forward() of each copies
+        them into a fresh arena and returns that arena's views (rounds 4-5 returned arena views here, which the
+        stream then updated in place, so a caller reusing the "constant" started its second stream on the first one's state)."""
+        return [torch.zeros(1, c, 2, h * k, w * k, dtype=dtype, device=self.device) for c, k in self._SHAPES]
+
+    def new_stream_cache(self, h, w):
+        """Opt-in fast form of `zero_cache` for ONE new stream: views of a fresh, zero-filled, registered arena, so the first
+        forward() finds its arena by lookup and neither allocates nor copies 32 slots of zeros.  SINGLE USE: forward() updates
+        these tensors in place - do not keep the list as a constant for further streams (use `zero_cache`), and mind that every
+        call takes one of the wrapper's `cache_streams` arena slots."""
+        if self.row_range(h) != (0, 8 * h):
+            raise NotImplementedError("the single-frame form decodes whole frames")
+        arena = self._new_arena(h, w)                      # zero-filled
+        views = self._cache_views(arena, (-arena.data_ptr()) % 256, h, w)[:self.NUM_CACHES]
+        assert [tuple(v.shape) for v in views] == [(1, c, 2, h * k, w * k) for c, k in self._SHAPES]
+        return views
 
     def forward(self, z, is_first_frame, *feat_cache):
         if self._w is None:

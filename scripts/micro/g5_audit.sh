@@ -3,10 +3,11 @@
 # accumulation registers named literally in inline asm, so the compiler must not place anything of its own there while they are
 # live - i.e. in front of the LAST accumulator read-out of the kernel (behind it the registers are dead and hipcc may, and does,
 # use them as spill space for the epilogue).  Also: no scratch, no spills, 3 x 40 matrix instructions in the K loop.
+# HIPCC / ARCH: the compiler and target the library itself was built with (csrc/Makefile honours the same variables).
 set -e
 cd "$(dirname "$0")/../../realtime_video_amd/csrc"
 OUT=${G5_AUDIT_DIR:-/tmp/g5_audit}; mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -S --cuda-device-only "$@" gemm5.hip -o $OUT/g5.s 2>&1 | grep -E "error|warning:" || true
+${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=${ARCH:-gfx950} -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -S --cuda-device-only "$@" gemm5.hip -o $OUT/g5.s 2>&1 | grep -E "error|warning:" || true
 for F in 0 1; do
   K="_ZN3rtv12gemm5_kernelILb${F}EEEvNS_10GemmParamsENS_9SplitArgsE"
   awk "/^$K:/,/^.Lfunc_end/" $OUT/g5.s > $OUT/k$F.s

@@ -2,10 +2,11 @@
 # Static audit of the one-wave-per-SIMD halo-tile convolution kernels (csrc/vae_conv.hip: conv_halo4_kernel, conv_halo4p_kernel), no GPU
 # needed: their accumulators and fragments live in accumulation registers named literally in inline asm, so the compiler must not place
 # anything of its own there (no accumulation-register reference outside ASMSTART / ASMEND), and there must be no scratch and no spills.
+# HIPCC / ARCH: the compiler and target the library itself was built with (csrc/Makefile honours the same variables).
 set -e
 cd "$(dirname "$0")/../../realtime_video_amd/csrc"
 OUT=${H4_AUDIT_DIR:-/tmp/h4_audit}; mkdir -p $OUT
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -S --cuda-device-only "$@" vae_conv.hip -o $OUT/vc.s 2>&1 | grep -E "error|warning: [a-z]" || true
+${HIPCC:-/opt/rocm/bin/hipcc} --offload-arch=${ARCH:-gfx950} -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -S --cuda-device-only "$@" vae_conv.hip -o $OUT/vc.s 2>&1 | grep -E "error|warning: [a-z]" || true
 for K in $(grep -o "^_ZN3rtv1[78]conv_halo4p\?_kernel[A-Za-z0-9_]*:" $OUT/vc.s | tr -d ':' | sort -u); do
   awk "/^$K:/,/^.Lfunc_end/" $OUT/vc.s > $OUT/k.s
   SP=$(awk "/\\.name: *$K\$/{f=1} f && /vgpr_spill_count:/{print \$2; exit}" $OUT/vc.s)

@@ -23,9 +23,12 @@ if which == "gemm":          # FFN-in: 4680 x 13824 x 5120, bias + GELU(tanh) ep
     ops.ensure_gemm_workspace(torch.device(dev))
     fn = lambda: ops.gemm(a, w, bias=b, act=ops.ACT_GELU_TANH, out=out, tile_cfg=gemm_cfg)
 elif which == "attn":        # denoise-step self-attention: 4680 queries x 9360 cached keys x 40 heads
+    # RTV_ATTN_LKV=32760: the whole cache window (max_attention_size, causal_model.py:192), K / V read in place from one layer's
+    # slice of the K/V-interleaved arena [rows, 2, H, 128] like the pipeline's cache (pipeline._initialize_kv_cache)
+    Lkv = int(os.environ.get("RTV_ATTN_LKV", 2 * M))
     q = torch.randn(1, M, H, 128, device=dev).to(torch.bfloat16)
-    k = torch.randn(1, 2 * M, H, 128, device=dev).to(torch.bfloat16)
-    v = torch.randn(1, 2 * M, H, 128, device=dev).to(torch.bfloat16)
+    arena = torch.randn(1, Lkv, 2, H, 128, device=dev).to(torch.bfloat16)
+    k, v = arena[:, :, 0], arena[:, :, 1]
     o = torch.empty_like(q)
     fn = lambda: ops.attn_fwd(q, k, v, out=o)
 elif which == "layernorm":   # LN + per-frame AdaLN modulation over [4680, 5120]

@@ -292,3 +292,112 @@ def test_fp8_weight_path_at_14b_width_matches_fp8_oracle(num_layers):
     assert abs(r["rel_l2_vs_bf16_oracle"] - noise) <= 0.1 * noise, r
     assert r["rel_l2_vs_fp8_oracle"] <= 0.8 * noise and r["rel_l2_vs_fp8_oracle"] <= 6e-2, r
     assert r["k_last_layer_rel_l2"] <= 1.0 * r["k_last_layer_fp8_oracle_vs_bf16_oracle"] and r["k_last_layer_rel_l2"] <= 9e-2, r
+
+
+# ------------------------------------------------------------------------------------ r06: the configurations VERDICT r05 named
+@pytest.mark.timeout(900)
+def test_full_width_layer_pipeline_inference_fills_the_32760_row_cache():
+    """north_star's "~25 GB KV cache" at production WIDTH through the drop-in boundary itself: `CausalInferencePipeline.inference`
+    (pipeline/causal_inference.py:48-277) on one layer of the 14B architecture (40 heads), `local_attn_size = -1`, the 32760-row
+    cache `_initialize_kv_cache` allocates (:284-289), 21 latent frames = 7 blocks of 3: every block runs four denoise forwards
+    and one clean-context forward over a window that grows by 4680 rows per block, and the last block attends ALL 32760 rows =
+    `max_attention_size` (wan/modules/causal_model.py:192, :388-389) with the one-wave-per-SIMD kernel on the arena's strided
+    rows.  Against `oracle.wan_oracle.pipeline_inference` (pinned to the reference pipeline's golden by the CPU suite) evaluated
+    in bf16 by torch eager on the device over the same weights and the same re-noising draws.  Stated tolerance: latents of every
+    block rel-L2 <= 2e-2 (the blocks are autoregressive: block b's context is the output of blocks < b), cache indices exact
+    (32760, 32760), sampled K / V rows of the whole cache rel-L2 <= 2e-2."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.pipeline import CausalInferencePipeline, make_args
+    model, wr, cfg = native_model("14b", text_dim=256, seed=5, num_layers=1)
+    sd = reference_state_dict(model)
+    g = torch.Generator().manual_seed(11)
+    ctx = torch.randn(40, 256, generator=g).to(torch.bfloat16).to(DEV)
+    noise = torch.randn(1, 21, 16, 60, 104, generator=g).to(torch.bfloat16).to(DEV)
+
+    def draws(seed):
+        rnd = torch.Generator().manual_seed(seed)
+        return lambda t: torch.randn(t.shape, generator=rnd, dtype=torch.bfloat16).to(t.device)
+
+    with torch.inference_mode():
+        ref, ref_kv = wo.pipeline_inference(sd, cfg, [ctx], noise, kv_size=32760, randn_like=draws(3))
+
+    class Text:
+        def __call__(self, text_prompts):
+            return {"prompt_embeds": [ctx]}
+
+    pipe = CausalInferencePipeline(make_args(num_frame_per_block=3, denoising_step_list=[1000, 750, 500, 250], context_noise=0),
+                                   DEV, generator=wr, text_encoder=Text(), vae=None)
+    pipe._randn_like = draws(3)
+    latents = pipe.inference(noise, ["a prompt"], return_latents=True)[1]
+    c = pipe.kv_cache1[0]
+    assert tuple(c["k"].shape) == (1, 32760, 40, 128)
+    assert (int(c["global_end_index"]), int(c["local_end_index"])) == \
+        (ref_kv[0]["global_end_index"], ref_kv[0]["local_end_index"]) == (32760, 32760)
+    errs = [rel_l2(latents[:, 3 * b:3 * b + 3], ref[:, 3 * b:3 * b + 3]) for b in range(7)]
+    print("32760-row pipeline.inference, per-block rel-L2 vs the bf16 oracle:", " ".join(f"{e:.2e}" for e in errs))
+    assert max(errs) <= 2e-2, errs
+    for name in ("k", "v"):
+        assert rel_l2(c[name][0, ::61], ref_kv[0][name][0, ::61]) <= 2e-2, name
+
+
+def run_config5_case(num_layers=2, blocks=64, world=8, exchange="heads", seed=4):
+    """BASELINE.json configs[4] as written - long-form: `num_blocks = 64`, `kv_cache_num_frames = 9`, the fp8 weight path, 8-way
+    context parallelism - at 14B width on `num_layers` layers: the native session with `enable_fp8()` under
+    `SimulatedContextParallel(8)` (all eight token shards in lockstep on this GPU: 585 rows per rank in the denoise forwards,
+    585 / 1170 / 1755 in the recompute forwards, 5 heads per rank under the head exchange) against the session oracle in the
+    row-sharded fp8 restatement (FP8_ROW_SHARDS: every rank quantises the rows it holds with its own dynamic scale), with the
+    bf16 session oracle beside it as the scale of the quantisation noise.  -> per-block rel-L2 figures."""
+    from oracle import wan_oracle as wo
+    from realtime_video_amd.parallel import SimulatedContextParallel
+    model, wr, cfg = native_model("14b", text_dim=256, seed=7, num_layers=num_layers)
+    sd = reference_state_dict(model)
+    sd8 = dict(sd)
+    sd8[wo.FP8_FLAG] = True
+    sd8[wo.FP8_ROW_SHARDS] = (world, (4680, 9360, 14040))
+    g = torch.Generator().manual_seed(13)
+    ctx = torch.randn(48, 256, generator=g).to(torch.bfloat16).to(DEV)
+    noise = torch.randn(1, 3 * blocks, 16, 60, 104, generator=g).to(torch.bfloat16).to(DEV)
+    oras = [wo.SessionOracle(w, cfg, [ctx], noise, kv_cache_num_frames=9, num_steps=4, shift=5.0, seed=seed) for w in (sd8, sd)]
+    model.context_parallel = SimulatedContextParallel(world, exchange)
+    model.enable_fp8()
+    sess, pipe = native_session(model, wr, 256, ctx, noise, blocks, seed, c=9)
+    rows = []
+    with torch.inference_mode():
+        for b in range(blocks):
+            out = sess.generate_block()
+            ref8, ref16 = (o.generate_block() for o in oras)
+            rows.append({"block": b, "ours_vs_fp8_oracle": rel_l2(out, ref8), "fp8_oracle_vs_bf16_oracle": rel_l2(ref8, ref16),
+                         "ours_vs_bf16_oracle": rel_l2(out, ref16), "finite": bool(torch.isfinite(out.float()).all())})
+    idx = [(int(c["global_end_index"]), int(c["local_end_index"])) for c in pipe.kv_cache1]
+    ref_idx = [(c["global_end_index"], c["local_end_index"]) for c in oras[0].kv_cache]
+    return {"rows": rows, "indices": idx, "ref_indices": ref_idx, "frames": (sess.current_start_frame, oras[0].current_start_frame),
+            "kv_rows": pipe.kv_cache1[0]["k"].shape[1]}
+
+
+@pytest.mark.timeout(1100)
+def test_config5_literal_64_blocks_c9_fp8_eight_way_context_parallel():
+    """BASELINE.json configs[4] literally (release_server.py:179-182 fp8, :563-576 / :588-633 the sliding recompute context,
+    `num_blocks = 64`, `kv_cache_num_frames = 9`, context parallel 8): two 14B-width layers, 64 blocks = 192 latent frames = 320
+    forwards per side.  From block 4 on the window slides (first frame + the last eight).  Stated tolerance (the fp8 rule of
+    `test_fp8_weight_path_at_14b_width_matches_fp8_oracle`, per block): ours is as far from the bf16 graph as the oracle's fp8 is
+    (within 15 %); the two fp8 implementations are closer to each other than 0.9 x that quantisation noise and than 6e-2 (the
+    unsharded rule says 0.8 x: here every linear has EIGHT rank-local dynamic scales instead of one, each of which re-rounds its
+    585 rows' e4m3 codes when upstream bf16 rounding moves that shard's maximum by an ulp - measured 0.75-0.83 x, flat:
+    3.2e-2 .. 3.5e-2 against 4.26e-2 of quantisation noise at blocks 0 / 8 / .. / 63, profiles/r06_config5_literal.log); and the
+    error does NOT GROW over the 64 blocks: the mean over the last 16 blocks is <= 1.25 x the mean over blocks 4..19 (the first
+    blocks with a full window).  Cache bookkeeping exact on every layer."""
+    r = run_config5_case()
+    rows = r["rows"]
+    for x in rows[::8] + rows[-1:]:
+        print("config 5 block %(block)2d: ours vs fp8 oracle %(ours_vs_fp8_oracle).3e   fp8 oracle vs bf16 oracle "
+              "%(fp8_oracle_vs_bf16_oracle).3e   ours vs bf16 oracle %(ours_vs_bf16_oracle).3e" % x)
+    assert all(x["finite"] for x in rows)
+    assert r["indices"] == r["ref_indices"] and r["indices"][0] == (18720, 18720) and r["kv_rows"] == 18720
+    assert r["frames"] == (192, 192)
+    for x in rows:
+        noise = x["fp8_oracle_vs_bf16_oracle"]
+        assert abs(x["ours_vs_bf16_oracle"] - noise) <= 0.15 * noise, x
+        assert x["ours_vs_fp8_oracle"] <= 0.9 * noise and x["ours_vs_fp8_oracle"] <= 6e-2, x
+    early = sum(x["ours_vs_fp8_oracle"] for x in rows[4:20]) / 16
+    late = sum(x["ours_vs_fp8_oracle"] for x in rows[-16:]) / 16
+    assert late <= 1.25 * early, (early, late)

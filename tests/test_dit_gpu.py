@@ -681,7 +681,7 @@ def test_config1_320x192_native_block_and_vae():
 
 
 def test_v_cache_rows_written_by_the_projection_gemm_equal_the_copied_ones():
-    """r05: the V third of the fused QKV projection goes into the V cache from the GEMM's epilogue (gemm_two_outputs, dit_forward.hip)
+    """r05: the V third of the fused QKV projection runs as a GEMM launch of its own whose output matrix IS the call's rows of the V cache (dit_layer_proj, csrc/dit_forward.hip)
     whenever the call's cache rows are one physical range; the RoPE / cache kernel then skips its V copy.  Pure data movement: flow
     prediction and the whole K / V cache must equal the r04 form (rtv_dit_set_direct_v(0): V copied out of the projection output) bit
     for bit - a denoise step at cache offset 0, the block-causal recompute pass, a second-block step at offset 4680."""

@@ -857,6 +857,25 @@ def test_attention_plugin_entries_run_on_device(ops, golden):
         plug.attention(q, kc, vc, causal=True)
 
 
+def test_attention_plugin_honours_key_lengths_or_refuses(ops):
+    """`k_lens` of the plug-in contract (wan/modules/attention.py:91-99, :119-147: the FlashAttention branch drops the keys at
+    positions >= k_lens[b]; the cross-attention of the non-causal model passes it, model.py:215): honoured exactly as a per-batch
+    key prefix, full lengths are the plain call bit for bit, and what cannot be honoured raises - nothing is silently ignored."""
+    from realtime_video_amd import attention as plug
+    q, k, v = _randn(2, 300, 3, 128, seed=1), _randn(2, 512, 3, 128, seed=2), _randn(2, 512, 3, 128, seed=3)
+    lens = torch.tensor([77, 512])
+    out = plug.attention(q, k, v, k_lens=lens)
+    for b, n in enumerate(lens.tolist()):
+        assert max_abs(out[b:b + 1], _attn_ref(q[b:b + 1], k[b:b + 1, :n], v[b:b + 1, :n])) <= 2e-2
+    assert rel_l2(out[0], plug.attention(q, k, v)[0]) > 1e-2                      # the mask matters for the short element
+    full = plug.attention(q, k, v, q_lens=torch.tensor([300, 300]), k_lens=torch.tensor([512, 512]))
+    assert torch.equal(full, plug.attention(q, k, v))
+    with pytest.raises(NotImplementedError):
+        plug.attention(q, k, v, q_lens=torch.tensor([300, 200]))
+    with pytest.raises(ValueError):
+        plug.attention(q, k, v, k_lens=torch.tensor([600, 512]))
+
+
 def test_attention_custom_op_opcheck():
     """torch.library.opcheck on `rtv::attn_fwd` (schema, fake-tensor propagation, AOT dispatch) - the registration the
     reference does for sageattention (sage.py:12-19) so that traced graphs survive."""
@@ -1076,3 +1095,28 @@ def test_attention_four_phase_kernel_strided_cache_views_full_size(ops):
     k, v = kc[:, 333:333 + 9360], vc[:, 333:333 + 9360]
     a, b = _both_schedules(ops, lambda: ops.attn_fwd(q, k, v))
     assert torch.equal(a, b) and torch.equal(ops.attn_fwd(q, k, v), b)
+
+
+# ----------------------------------------------------------------------------------------- r06: the whole 32760-row cache at 40 heads
+def test_attention_full_cache_window_32760_rows_at_14b_width(ops):
+    """north_star's "~25 GB KV cache" operating point at the kernel: the largest window the reference ever attends -
+    `max_attention_size` = 32760 rows (wan/modules/causal_model.py:192, :388-389), the size pipeline/causal_inference.py:284-289
+    allocates - at the 14B's 40 heads, 4680 query rows, K and V read IN PLACE from one layer's slice of the cache arena
+    ([rows, 2, H, 128]: K and V of a row side by side, row stride 2 x the model width, pipeline._initialize_kv_cache).
+    (1) against the fp32 definition on sampled heads, stated tolerance 2e-2 max-abs / 1e-2 rel-L2 on unit-variance data;
+    (2) the one-wave-per-SIMD kernel (the default for this shape) == the four-phase kernel == the lockstep kernel, bit for bit;
+    (3) the window as two physical ranges of the same rows (a ring that wrapped at row 20000) == the single range."""
+    H, Lq, Lkv = 40, 4680, 32760
+    arena = _randn(1, Lkv, 2, H, 128, seed=2)
+    k, v = arena[:, :, 0], arena[:, :, 1]
+    assert k.stride(1) == 2 * H * 128 and not k.is_contiguous()
+    q = _randn(1, Lq, H, 128, seed=1)
+    a, b = _both_schedules(ops, lambda: ops.attn_fwd(q, k, v))
+    out = ops.attn_fwd(q, k, v)
+    assert torch.equal(a, b) and torch.equal(out, b)
+    for h in (0, 23, 39):
+        ref = _attn_ref(q[:, :, h:h + 1], k[:, :, h:h + 1], v[:, :, h:h + 1])
+        assert max_abs(out[:, :, h:h + 1], ref) <= 2e-2
+        assert rel_l2(out[:, :, h:h + 1], ref) <= 1e-2
+    two = ops.attn_fwd_win(q, k, v, (0, 20000), (20000, Lkv - 20000))
+    assert torch.equal(two, out)

@@ -330,8 +330,8 @@ def test_single_frame_decoder_wrapper_matches_reference_golden(golden):
     dec.load_state_dict(vo.make_vae_weights(seed=0))
     w16 = {k: v.half().to(DEV) for k, v in vo.make_vae_weights(seed=0).items()}
     zs = vae_inputs(seed=23)[0][:, :3]
-    cache = dec.zero_cache(8, 12)
-    arenas0, slot0 = len(dec._arenas._by_ptr), cache[0].data_ptr()      # zero_cache() hands out views of a registered arena ...
+    cache = dec.new_stream_cache(8, 12)
+    arenas0, slot0 = len(dec._arenas._by_ptr), cache[0].data_ptr()      # new_stream_cache() hands out views of a registered arena ...
     cache16 = vo.single_zero_cache(8, 12, torch.float16, DEV)
     for i in range(3):
         first = torch.tensor([1.0 if i == 0 else 0.0], device=DEV, dtype=torch.float16)     # vae_torch2trt.py:167,174
@@ -351,6 +351,31 @@ def test_single_frame_decoder_wrapper_matches_reference_golden(golden):
             assert max_abs(c[0, ::7, :, ::3, ::5].float().cpu(), gs) <= 2e-2 + 2e-2 * float(gs.abs().max()), i
     with pytest.raises(ValueError):
         dec(zs[:, :1].half().to(DEV), True, *([None] * 32))
+
+
+def test_single_frame_decoder_zero_cache_is_a_reusable_constant():
+    """The reference keeps the zero caches as a constant and starts EVERY stream from it (`feat_cache = ZERO_VAE_CACHE`,
+    demo_utils/vae_torch2trt.py:168; demo_utils/constant.py:6-39).  `zero_cache()` therefore returns plain tensors that stay zero:
+    two streams started from the same list give the same first-frame pixels bit for bit, the list is still all zeros afterwards,
+    and the streams do not share state (an arena-backed list was updated in place by the first stream)."""
+    from realtime_video_amd.vae_decoder import VAEDecoderWrapperSingle
+    dec = VAEDecoderWrapperSingle(DEV).init_random_weights(seed=3)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    z = [torch.randn(1, 1, 16, 8, 12, generator=g).half().to(DEV) for _ in range(3)]
+    zero = dec.zero_cache(8, 12)
+    px_a0, cache_a = dec(z[0], True, *zero)
+    px_a1, cache_a = dec(z[1], False, *cache_a)
+    assert all(float(c.abs().max()) == 0.0 for c in zero)                       # the constant is untouched
+    px_b0, cache_b = dec(z[0], True, *zero)                                     # second stream from the SAME list
+    assert torch.equal(px_a0, px_b0)
+    assert cache_b[0].data_ptr() != cache_a[0].data_ptr()                       # its own arena
+    px_b1, cache_b = dec(z[1], False, *cache_b)
+    assert torch.equal(px_a1, px_b1)
+    px_a2, _ = dec(z[2], False, *cache_a)                                       # stream a continues unaffected by stream b
+    px_b2, _ = dec(z[2], False, *cache_b)
+    assert torch.equal(px_a2, px_b2)
+    one_shot = dec.new_stream_cache(8, 12)                                      # the in-place form gives the same first frame
+    assert torch.equal(dec(z[0], True, *one_shot)[0], px_a0)
 
 
 def test_cloned_feature_cache_continues_the_stream_and_foreign_cache_is_refused():
