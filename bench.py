@@ -151,6 +151,10 @@ def main():
                     help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
                          "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
                          "launch-gap cost, not the contract line")
+    ap.add_argument("--no-hipgraph", action="store_true",
+                    help="context-parallel runs (--gpus N > 1) replay every DiT forward - kernels AND RCCL collectives - from captured "
+                         "hipGraphs by default (the host side of a rank is 47 ms per block eager, 21 ms under replay, of ~120 ms of GPU "
+                         "work at 8 ranks: profiles/r05_cp_host_probe.txt); this flag keeps them eager (A/B)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5's weight path (reference enable_fp8: e4m3 weights + dynamic per-tensor e4m3 "
                          "activations in every nn.Linear).  NOT the headline precision: the line is flagged dtype fp8 and "
@@ -251,6 +255,14 @@ def main():
         model.enable_fp8()
     use_cp = (world > 1 and args.parallel == "cp") or args.cp_host_probe
     cp_world = world if use_cp else max(1, args.simulate_cp)
+    # Context-parallel runs replay from hipGraphs by DEFAULT (r06): at N ranks the GPU work per block shrinks
+    # N-fold and the ~2650 launches + ~600 collectives a rank issues per block do not.  The kernel-class brackets cannot live inside
+    # a graph, so the timed region carries none; a DIAGNOSTIC block behind the timed region runs eagerly with every bracket on and
+    # with the exposed-communication brackets of parallel.ContextParallel (config.cp_diagnostics).  Not over gloo (shared-GPU rigs).
+    cp_graphs = world > 1 and use_cp and not args.no_hipgraph and not shared_gpu and not args.cp_host_probe
+    if cp_graphs and not args.hipgraph:
+        model.use_hip_graphs = True
+        args.profile_classes = "none"
     if args.cp_attn_splits <= 0:   # the count that fills the 256 CUs best for this rank count (parallel.attn_kv_splits_for)
         from realtime_video_amd.parallel import attn_kv_splits_for
         args.cp_attn_splits = attn_kv_splits_for(cp_world, mc["num_heads"],
@@ -303,7 +315,11 @@ def main():
     prompt[:, :64] = torch.randn(1, 64, 4096, generator=g, device=dev).to(torch.bfloat16)
     models = Models(transformer=wr, pipeline=pipe, text_encoder=StaticTextEncoder(prompt), vae_decoder=vae,
                     vae_encoder=vae_enc)
-    n_blocks = args.warmup + args.steps
+    diag_blocks = 1 if use_cp else 0      # one eager, fully bracketed block behind the timed region (untimed; --cp-host-probe too)
+    # (the session's noise tensor is drawn in one call whose values depend on its SIZE - the generator's grid follows numel - so every
+    # run reserves the diagnostic block, context parallel or not: an N-rank run and the single-GPU run of the same command see the same
+    # noise and their last timed block can be compared bit for bit, tests/test_context_parallel_gpu.py)
+    n_blocks = args.warmup + args.steps + 1
     params = GenerateParams(prompt="synthetic", seed=42, kv_cache_num_frames=args.kv_cache_num_frames,
                             num_blocks=n_blocks, num_denoising_steps=args.denoising_steps, keep_first_frame=keep_first)
     # frame delivery (release_server.py:978-991): every block's pixels go to pinned host memory as rgb8 on the download
@@ -388,6 +404,75 @@ def main():
         v["ms"] = max(v["ms"] - bracket_ms * v["launches"], 0.0)
         v["ms_class"] = v["ms"] * (v["seen_work"] / v["work"] if v["work"] > 0 else 1.0)
     peak_mem = torch.cuda.max_memory_allocated(dev)
+    # ---- context parallel: the diagnostic block (eager, every kernel class bracketed, exposed-communication brackets on), then one
+    # record per rank gathered to rank 0.  Outside the timed region; its brackets serialise neighbouring launches, so its own wall
+    # time is not a throughput figure - the per-class kernel times and the waits for collectives are what it is for.
+    cp_diag = None
+    if diag_blocks:
+        cpo = model.context_parallel
+        graphs_were = model.use_hip_graphs
+        model.use_hip_graphs = False
+        wr.on = False
+        barrier()
+        ops.prof_reset()
+        for cls in ("gemm", "attn", "layernorm", "rope", "conv", "misc"):
+            ops.prof_set_stride(cls, 1)
+        ops.prof_enable(True, None)
+        cpo.start_timing()
+        td = time.perf_counter()
+        sess.generate_block()
+        host_diag_ms = 1e3 * (time.perf_counter() - td)
+        if tickets:
+            downloader.fetch(tickets.pop())
+        torch.cuda.synchronize()
+        wall_diag_ms = 1e3 * (time.perf_counter() - td)
+        ops.prof_enable(False)
+        exposed = cpo.read_timing()
+        model.use_hip_graphs = graphs_were
+        bms = ops.prof_bracket_overhead(256)
+        kinds = ["exchange_q", "exchange_kv", "exchange_o", "gather_kv", "head_rows", "vae_pixel_rows", "all_gather_rows", "all_to_all"]
+        classes = ["gemm", "attn", "layernorm", "rope", "conv", "misc"]
+        rec = []
+        for c in classes:
+            pr = ops.prof_read(c)
+            rec.append(max(pr["ms"] - bms * pr["launches"], 0.0))
+        for k in kinds:
+            n, ms = exposed.get(k, (0, 0.0))
+            rec += [float(n), max(ms - bms * n, 0.0)]
+        rec += [host_diag_ms, wall_diag_ms, host_ms["launch_issue"], host_ms["loop"]]
+        mine = torch.tensor(rec, device=dev, dtype=torch.float64)
+        allr = torch.empty((world, mine.numel()), device=dev, dtype=torch.float64)
+        if shared_gpu:      # gloo rig: gather through the host
+            parts = [torch.empty(mine.numel(), dtype=torch.float64) for _ in range(world)]
+            torch.distributed.all_gather(parts, mine.cpu())
+            allr = torch.stack(parts)
+        else:
+            torch.distributed.all_gather_into_tensor(allr, mine)
+        allr = allr.cpu().tolist()
+        L, fwd = mc["num_layers"], args.denoising_steps + 1
+        per_rank = []
+        for r in range(world):
+            row = allr[r]
+            kern = dict(zip(classes, row[:len(classes)]))
+            ex, off = {}, len(classes)
+            for i, k in enumerate(kinds):
+                n, ms = row[off + 2 * i], row[off + 2 * i + 1]
+                if n:
+                    ex[k] = {"waits": int(n), "ms_per_block": ms}
+            tail = row[off + 2 * len(kinds):]
+            per_layer = sum(v["ms_per_block"] for k, v in ex.items() if k in ("exchange_q", "exchange_kv", "exchange_o", "gather_kv"))
+            per_rank.append({"rank": r, "kernel_ms_per_block": kern, "kernel_ms_per_block_sum": sum(kern.values()),
+                             "exposed_collective_ms_per_block": ex, "exposed_collective_ms_per_block_sum": sum(v["ms_per_block"] for v in ex.values()),
+                             "exposed_collective_ms_per_layer": per_layer / (L * fwd),
+                             "host_ms_diagnostic_block_eager": tail[0], "wall_ms_diagnostic_block_eager": tail[1],
+                             "host_launch_issue_ms_per_timed_block": tail[2], "host_loop_ms_per_timed_block": tail[3]})
+        cp_diag = {"what": "ONE eager block behind the timed region on every rank: all kernel classes bracketed with hipEvents (bracket "
+                           "overhead subtracted), and every point where the compute stream waits for a collective bracketed on that "
+                           "stream - Pending.wait() of the asynchronous exchanges (what the overlap did not hide), the whole call of the "
+                           "synchronous ones (exchange_o, head rows, VAE pixel rows).  per-layer = the four per-layer exchanges / "
+                           f"({L} layers x {fwd} forwards)",
+                   "timed_region": "hipGraph replay (kernels + RCCL collectives captured per forward geometry)" if graphs_were else "eager",
+                   "per_rank": per_rank}
     if rank != 0:
         return
     total_frames = frames if use_cp or world == 1 else frames * world  # replicas: every rank generates its own stream
@@ -434,6 +519,8 @@ def main():
                 f"sharded by output rows ({world} stripes + conv halos, one pixel all-gather per block), first-frame "
                 f"re-encode replicated" if use_cp else f"{world} independent replicas"),
             "cp_attn_kv_splits": args.cp_attn_splits if (use_cp or args.simulate_cp > 1) else None,
+            "cp_hipgraph_replay": bool(model.use_hip_graphs) if use_cp else None,
+            "cp_diagnostics": cp_diag,
             "dit_ms_per_denoise_step": sum(step_ms) / max(1, len(step_ms)),        # BASELINE.json "per-step DiT latency"
             "dit_ms_per_recompute_forward": sum(recompute_ms) / max(1, len(recompute_ms)) if recompute_ms else None,
             # kernel-class times exist only for the classes bracketed with events (--profile-classes; 'all' = diagnostic)

@@ -717,7 +717,7 @@ class CausalWanModel:
                     hrow = torch.empty((M, self.out_dim * 4), dtype=torch.bfloat16, device=u.device)
                     for st, wsa in parts:
                         _lib.call("rtv_dit_head", cfg_p, w_p, ctypes.byref(st), c_vp(hrow.data_ptr()), *wsa)
-                    cp.all_gather_rows_(hrow)
+                    cp.all_gather_rows_(hrow, kind="head_rows")
                     _lib.call("rtv_dit_finish", cfg_p, ctypes.byref(parts[0][0]), c_vp(hrow.data_ptr()), stream)
 
             if graph_key is not None and self._graphs.get(graph_key) == "seen":

@@ -423,7 +423,8 @@ static int dit_after_attn(Ctx& c, int l) {
 //   o_recv  [world][rc][gc]       attention output of the local rows, one block per head group
 // In these phases step->kv_k / kv_v point at THIS RANK'S heads ([kv_size][H/world][128], row stride kv_row_stride).
 static int hp_check(Ctx& c, int world) {
-  if (world <= 1 || c.H % world) return set_error(-1, "dit: head-parallel exchange needs num_heads % world == 0");
+  // (world == 1 is the degenerate one-rank exchange: bench.py --cp-host-probe runs the whole head-parallel path on a one-rank group)
+  if (world < 1 || c.H % world) return set_error(-1, "dit: head-parallel exchange needs num_heads % world == 0");
   if (c.M % world || c.rc != c.M / world || c.r0 % c.rc)
     return set_error(-1, "dit: head-parallel exchange needs equal token shards (M % world == 0)");
   return 0;

@@ -32,12 +32,16 @@ def shard_rows(M, world, rank):
 
 class _ExchangeChoice:
     exchange = "auto"
+    # A ONE-rank group normally takes no collective at all.  True (bench.py --cp-host-probe): it runs the context-parallel code
+    # path in full - head exchange, every collective issued on the one-rank group as a self-exchange through the same
+    # torch.distributed / RCCL host path, fences and all - so that the host cost of a rank can be measured on a one-GPU box.
+    force_single_rank = False
 
     def head_exchange(self, num_heads):
         """True when self-attention runs head-sharded (all-to-all exchange) for a model with `num_heads` heads."""
         if self.exchange not in ("auto", "heads", "rows"):
             raise ValueError(f"unknown exchange {self.exchange!r}")
-        if self.world == 1 or self.exchange == "rows":
+        if (self.world == 1 and not self.force_single_rank) or self.exchange == "rows":
             return False
         if num_heads % self.world:
             if self.exchange == "heads":
@@ -63,14 +67,18 @@ def attn_kv_splits_for(world, num_heads, q_tiles=19, cus=None):
 class Pending:
     """A collective in flight (issued with async_op=True on the process group's communication stream, RCCL running beside the
     compute stream) plus the work that has to follow it; `wait()` makes the CURRENT stream wait for it - the host does not
-    block - and runs the follow-up.  `Pending()` is an already completed exchange."""
+    block - and runs the follow-up.  `Pending()` is an already completed exchange.  `timer` = (ContextParallel, kind): the wait
+    is bracketed with events on the compute stream when that object collects timings (`ContextParallel.start_timing`)."""
 
-    def __init__(self, work=None, after=None):
-        self.work, self.after = work, after
+    def __init__(self, work=None, after=None, timer=None):
+        self.work, self.after, self.timer = work, after, timer
 
     def wait(self):
         if self.work is not None:
-            self.work.wait()
+            if self.timer is not None and self.timer[0].timing is not None:
+                self.timer[0]._bracket(self.timer[1], self.work.wait)
+            else:
+                self.work.wait()
             self.work = None
         if self.after is not None:
             self.after()
@@ -95,6 +103,7 @@ class ContextParallel(_ExchangeChoice):
         # sharded forward is bit-identical with the unsharded one (what the tests assert); with more it differs by fp32
         # summation order.
         self.attn_kv_splits = int(attn_kv_splits)
+        self.timing = None        # start_timing(): list of (kind, start event, stop event)
 
     def shard(self, M):
         return shard_rows(M, self.world, self.rank)
@@ -102,11 +111,44 @@ class ContextParallel(_ExchangeChoice):
     def local_ranks(self):
         return [self.rank]
 
-    def all_gather_rows_(self, buf, async_op=False):
+    # ---- exposed-communication diagnostics (bench.py --gpus N)
+    def start_timing(self):
+        """From here on every point where the COMPUTE stream has to wait for a collective is bracketed with two events on that
+        stream: the `Pending.wait()` of an asynchronous exchange (what the overlap did not hide) and the whole call of a
+        synchronous one (`exchange_o`, the head-row gather: exposed by construction).  Eager forwards only - events inside a
+        captured graph cannot be timed.  `read_timing()` -> {kind: (count, total ms)}."""
+        self.timing = []
+
+    def _bracket(self, kind, fn):
+        if self.timing is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.timing.append((kind, e0, e1))
+        return out
+
+    def read_timing(self, stop=True):
+        torch.cuda.synchronize()
+        out = {}
+        for kind, e0, e1 in self.timing or []:
+            n, ms = out.get(kind, (0, 0.0))
+            out[kind] = (n + 1, ms + e0.elapsed_time(e1))
+        if stop:
+            self.timing = None
+        return out
+
+    def all_gather_rows_(self, buf, async_op=False, kind="all_gather_rows"):
         """In-place all-gather along dim 0 of a contiguous buffer whose local shard is already filled.  async_op: returns a
         Pending (the collective runs on the communication stream; wait() orders the current stream behind it)."""
+        if self.timing is not None and not async_op:
+            return self._bracket(kind, lambda: self._all_gather_rows_(buf, False, kind))
+        return self._all_gather_rows_(buf, async_op, kind)
+
+    def _all_gather_rows_(self, buf, async_op, kind):
         done = Pending() if async_op else buf
-        if self.world == 1:
+        if self.world == 1 and not self.force_single_rank:
             return done
         if not buf.is_contiguous() or buf.shape[0] % self.world:
             raise ValueError("all_gather_rows_ needs a contiguous buffer with rows divisible by the world size")
@@ -123,17 +165,17 @@ class ContextParallel(_ExchangeChoice):
             work = dist.all_gather([buf[r * n:(r + 1) * n] for r in range(self.world)], mine.clone(), group=self.group,
                                    async_op=async_op and self.overlap)
             if async_op:
-                return Pending(work if self.overlap else None)
+                return Pending(work if self.overlap else None, timer=(self, kind))
         else:
             work = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=async_op and self.overlap)
             if async_op:
-                return Pending(work if self.overlap else None)
+                return Pending(work if self.overlap else None, timer=(self, kind))
         return done
 
     def gather_kv(self, k, v, row0, M, async_op=False):
         """All-gather cache rows [row0, row0+M) of one layer's K and V ([kv_size, H, hd] views).  If K and V rows
         are interleaved in one arena ([kv_size, 2, H, hd]) this is ONE collective, otherwise two."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_single_rank:
             return Pending() if async_op else None
         H, hd = k.shape[1], k.shape[2]
         row = H * hd
@@ -141,17 +183,22 @@ class ContextParallel(_ExchangeChoice):
                  v.data_ptr() == k.data_ptr() + row * k.element_size())
         if inter:
             both = torch.as_strided(k, (M, 2 * row), (2 * row, 1), k.storage_offset() + row0 * 2 * row)
-            pend = self.all_gather_rows_(both, async_op)
+            pend = self.all_gather_rows_(both, async_op, kind="gather_kv")
             return pend if async_op else None
         if k.stride(0) != row or v.stride(0) != row:
             raise ValueError("gather_kv needs dense or K/V-interleaved cache rows")
-        p1 = self.all_gather_rows_(k[row0:row0 + M], async_op)
-        p2 = self.all_gather_rows_(v[row0:row0 + M], async_op)
+        p1 = self.all_gather_rows_(k[row0:row0 + M], async_op, kind="gather_kv")
+        p2 = self.all_gather_rows_(v[row0:row0 + M], async_op, kind="gather_kv")
         return Pending(after=lambda: (p1.wait(), p2.wait())) if async_op else None
 
     # ---- head exchange
-    def all_to_all_(self, out, inp, async_op=False):
+    def all_to_all_(self, out, inp, async_op=False, kind="all_to_all"):
         """out[g-th block] <- rank g's inp[rank-th block]; both contiguous with dim 0 divisible by the world size."""
+        if self.timing is not None and not async_op:
+            return self._bracket(kind, lambda: self._all_to_all_(out, inp, False, kind))
+        return self._all_to_all_(out, inp, async_op, kind)
+
+    def _all_to_all_(self, out, inp, async_op, kind):
         if not out.is_contiguous() or not inp.is_contiguous() or out.numel() != inp.numel() or out.numel() % self.world:
             raise ValueError("all_to_all_ needs contiguous, equally sized buffers divisible by the world size")
         work = None
@@ -161,12 +208,12 @@ class ContextParallel(_ExchangeChoice):
             out.view(-1).copy_(host_out)
         else:
             work = dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group, async_op=async_op and self.overlap)
-        return Pending(work if (async_op and self.overlap) else None) if async_op else out
+        return Pending(work if (async_op and self.overlap) else None, timer=(self, kind)) if async_op else out
 
     def exchange_q(self, parts, async_op=False):
         """q_send -> q_all: every rank receives ALL query rows of its own heads."""
         (rank, b), = parts
-        return self.all_to_all_(b["q_all"], b["q_send"], async_op)
+        return self.all_to_all_(b["q_all"], b["q_send"], async_op, kind="exchange_q")
 
     def exchange_kv(self, parts, k, v, row0, M, async_op=False):
         """kv_send -> rows [row0, row0+M) of this rank's heads of one layer's K/V cache (k, v: [kv_size, hn or H, hd] views)."""
@@ -175,9 +222,9 @@ class ContextParallel(_ExchangeChoice):
         h0 = 0 if k.shape[1] == hn else rank * hn
         rows = _interleaved_rows(k, v, row0, M, h0, hn)
         if rows is not None:
-            return self.all_to_all_(rows, b["kv_send"], async_op)            # straight into the cache arena
+            return self.all_to_all_(rows, b["kv_send"], async_op, kind="exchange_kv")            # straight into the cache arena
         tmp = torch.empty_like(b["kv_send"])
-        pend = self.all_to_all_(tmp, b["kv_send"], async_op)
+        pend = self.all_to_all_(tmp, b["kv_send"], async_op, kind="exchange_kv")
 
         def scatter():
             t = tmp.view(M, 2, hn, hd)
@@ -195,7 +242,7 @@ class ContextParallel(_ExchangeChoice):
 
     def exchange_o(self, parts):
         (rank, b), = parts
-        self.all_to_all_(b["o_recv"], b["o_all"])
+        self.all_to_all_(b["o_recv"], b["o_all"], kind="exchange_o")
 
 
 def _interleaved_rows(k, v, row0, M, h0, hn):
@@ -218,6 +265,7 @@ class SimulatedContextParallel(_ExchangeChoice):
         self.world, self.rank = world, 0
         self.exchange = exchange
         self.attn_kv_splits = int(attn_kv_splits)
+        self.timing = None
 
     def shard(self, M):
         return shard_rows(M, self.world, 0)
@@ -225,7 +273,7 @@ class SimulatedContextParallel(_ExchangeChoice):
     def local_ranks(self):
         return list(range(self.world))
 
-    def all_gather_rows_(self, buf, async_op=False):
+    def all_gather_rows_(self, buf, async_op=False, kind="all_gather_rows"):
         return Pending() if async_op else buf
 
     def gather_kv(self, k, v, row0, M, async_op=False):
@@ -307,7 +355,7 @@ def gather_row_stripes(cp, stripe, H):
     rows_max = max(b - a for a, b in bounds)
     buf = torch.zeros((n, T, C, rows_max, W), dtype=stripe.dtype, device=stripe.device)
     buf[cp.rank, :, :, :stripe.shape[2]] = stripe
-    cp.all_gather_rows_(buf)
+    cp.all_gather_rows_(buf, kind="vae_pixel_rows")
     if all(b - a == rows_max for a, b in bounds):
         return buf.permute(1, 2, 0, 3, 4).reshape(T, C, H, W)
     return torch.cat([buf[r, :, :, :b - a] for r, (a, b) in enumerate(bounds)], dim=2)

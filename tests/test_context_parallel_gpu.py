@@ -137,3 +137,41 @@ def test_eight_rank_bench_launcher_path_equals_single_process(exchange):
     a, b = one["config"]["last_block_latents_checksum"], eight["config"]["last_block_latents_checksum"]
     assert a["shape"] == b["shape"] == [1, 3, 16, 60, 104]
     assert a["sha256_bf16"] == b["sha256_bf16"], (a, b)
+
+
+@pytest.mark.timeout(600)
+def test_bench_context_parallel_line_carries_per_rank_diagnostics():
+    """`bench.py --gpus N` is the first thing that will ever run on real xGMI, so its one JSON line has to be enough to diagnose that
+    run: per rank the kernel time per class, the time the compute stream WAITED for each kind of collective
+    (per block and per layer) and the host time.  Exercised here on what a one-GPU box offers: (a) two ranks sharing cuda:0 over
+    gloo through the launcher path (eager: the gloo route cannot be captured), (b) a one-rank RCCL group with the forwards replayed
+    from hipGraphs - the default of a real N-rank run - followed by the eager diagnostic block."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+
+    def run(args, **extra):
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args + ["--steps", "1", "--warmup", "2", "--no-cpu-baseline"],
+                             capture_output=True, text=True, env=dict(env, **extra), timeout=500, cwd=root)
+        assert res.returncode == 0, res.stderr[-3000:]
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+
+    two = run(["--gpus", "2", "--model", "tiny"], RTV_BENCH_SHARED_GPU="1")
+    d = two["config"]["cp_diagnostics"]
+    assert two["config"]["cp_hipgraph_replay"] is False and d["timed_region"] == "eager" and len(d["per_rank"]) == 2
+    for r, rec in enumerate(d["per_rank"]):
+        assert rec["rank"] == r and rec["kernel_ms_per_block"]["gemm"] > 0 and rec["kernel_ms_per_block"]["attn"] > 0
+        ex = rec["exposed_collective_ms_per_block"]
+        assert {"exchange_o", "head_rows", "vae_pixel_rows"} <= set(ex)           # the synchronous ones are always bracketed
+        assert ex["exchange_o"]["waits"] == 2 * 5 - 1                             # 2 layers x 5 forwards, minus the kv-only last layer
+        assert rec["exposed_collective_ms_per_layer"] > 0 and rec["host_launch_issue_ms_per_timed_block"] > 0
+    one = run(["--cp-host-probe", "--hipgraph"])
+    d = one["config"]["cp_diagnostics"]
+    assert one["config"]["cp_hipgraph_replay"] is True and d["timed_region"].startswith("hipGraph replay")
+    rec = d["per_rank"][0]
+    assert rec["kernel_ms_per_block"]["gemm"] > 0 and set(rec["exposed_collective_ms_per_block"]) >= {"exchange_q", "exchange_kv", "exchange_o"}
+    assert rec["exposed_collective_ms_per_block"]["exchange_q"]["waits"] == 40 * 5 - 1
