@@ -56,6 +56,39 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 __device__ unsigned long long* g_timeline = nullptr;   // [grid][4]: realtime start, after K loop, end, (seg << 32 | tile)
 #endif
 
+// tile id -> (row tile, column tile): 8-row supertiles, so that the 32 tiles an XCD runs at a time (consecutive ids, xcd_remap)
+// share A / W panels through its L2.  RTV_G8_BALANCED_GROUPS (A/B build): the rows balanced over ceil(tiles_m / 8) groups (19 row
+// tiles: 7 + 6 + 6 instead of 8 + 8 + 3) - a 3-row group makes an XCD-round 3 x 10.7 tiles = 13.7 operand panels instead of 12
+// (scripts/gemm_traffic_model.py: qk 3.74 -> 3.54 x, ffn-in 4.40 -> 4.04 x the algorithmic bytes).  Same arithmetic per tile.
+__device__ __forceinline__ void g8_tile_mn(int tiles_m, int tiles_n, int tile_id, int* mt, int* nt) {
+#if RTV_G8_BALANCED_GROUPS
+  const int ngrp = (tiles_m + 7) >> 3;
+  const int gq = tiles_m / ngrp, gr = tiles_m - gq * ngrp;   // the first gr groups have gq + 1 rows
+  const int big = (gq + 1) * tiles_n;
+  int first_m, gm, in_group;
+  if (tile_id < gr * big) {
+    const int group = tile_id / big;
+    gm = gq + 1;
+    first_m = group * gm;
+    in_group = tile_id - group * big;
+  } else {
+    const int t = tile_id - gr * big, sm = gq * tiles_n, group = t / sm;
+    gm = gq;
+    first_m = gr * (gq + 1) + group * gq;
+    in_group = t - group * sm;
+  }
+#else
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n;
+  const int group = tile_id / per_group;
+  const int first_m = group * GROUP_M;
+  const int gm = min(tiles_m - first_m, GROUP_M);
+  const int in_group = tile_id - group * per_group;
+#endif
+  *mt = first_m + in_group % gm;
+  *nt = in_group / gm;
+}
+
 // (the 128 x 256 body, defined below: gemm8_kernel runs the half-tile units of its tail round through it)
 template <bool F16>
 __device__ __forceinline__ void gemm8m_body(const GemmParams& p, const SplitArgs& sp, int m0, int n0, int tile_id, int seg, int unit,
@@ -89,15 +122,11 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
     if (bid0 >= sp.first_unit) {
       const int v = xcd_remap(bid0 - sp.first_unit, nhu);   // the two halves of a tile side by side on one XCD (they share W)
       const int tile_id = sp.first_unit + (v >> 1);
-      constexpr int GROUP_M = 8;
-      const int per_group = GROUP_M * p.tiles_n;
-      const int group = tile_id / per_group;
-      const int first_m = group * GROUP_M;
-      const int gm = min(p.tiles_m - first_m, GROUP_M);
-      const int in_group = tile_id - group * per_group;
-      const int m0h = (first_m + in_group % gm) * BM + (v & 1) * 128;
+      int mt, nt;
+      g8_tile_mn(p.tiles_m, p.tiles_n, tile_id, &mt, &nt);
+      const int m0h = mt * BM + (v & 1) * 128;
       if (m0h >= p.M) return;                                // the lower half of a ragged last row of tiles has no rows
-      gemm8m_body<F16>(p, sp, m0h, (in_group / gm) * BN, tile_id, 0, -1, 0, p.K / BK, false);
+      gemm8m_body<F16>(p, sp, m0h, nt * BN, tile_id, 0, -1, 0, p.K / BK, false);
       return;
     }
     sp.S = 1;             // the full tiles below: plain mapping of bid0
@@ -121,14 +150,10 @@ __global__ __launch_bounds__(g8::THREADS, 2) void gemm8_kernel(GemmParams p, Spl
   int tile_id, seg, unit, kt_begin, kt_end;
   const bool is_split = split_unit_of_block(sp, bid0, nk_total, &tile_id, &unit, &seg, &kt_begin, &kt_end);
   // tile id -> (m, n): GROUP_M-row supertiles so concurrently running tiles share A / W panels in L2
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * p.tiles_n;
-  const int group = tile_id / per_group;
-  const int first_m = group * GROUP_M;
-  const int gm = min(p.tiles_m - first_m, GROUP_M);
-  const int in_group = tile_id - group * per_group;
-  const int m0 = (first_m + in_group % gm) * BM;
-  const int n0 = (in_group / gm) * BN;
+  int mt_, nt_;
+  g8_tile_mn(p.tiles_m, p.tiles_n, tile_id, &mt_, &nt_);
+  const int m0 = mt_ * BM;
+  const int n0 = nt_ * BN;
   // ---- DMA geometry: a half-tile is 2 wave-wide pieces per wave; piece j of wave w fills rows j*64 + w*8 .. +8
   //      (lane -> row + lane/8, chunk slot lane%8), source chunk pre-swizzled.  BYTE offsets at k = 0.
   uint32_t src_off[4][2];  // [A0, A1, W0, W1][j]

@@ -1,4 +1,5 @@
-"""Run one GEMM shape a few times (for rocprofv3 --pmc passes). usage: one_gemm.py cfg [M N K] [iters]"""
+"""Run one GEMM shape a few times (for rocprofv3 --pmc passes). usage: one_gemm.py cfg [M N K] [iters] [res]
+res = 1: the fused `x + y` residual epilogue (the o / cross-o / ffn-out projections read the residual stream and write it in place)"""
 import os
 import sys
 
@@ -15,6 +16,7 @@ a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
 w = (torch.randn(n, k, device="cuda") * k ** -0.5).to(torch.bfloat16)
 b = torch.randn(n, device="cuda").to(torch.bfloat16)
 out = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
+res = len(sys.argv) > 6 and sys.argv[6] == "1"
 for _ in range(iters):
-    ops.gemm(a, w, bias=b, out=out, tile_cfg=cfg)
+    ops.gemm(a, w, bias=b, out=out, tile_cfg=cfg, residual=out if res else None)
 torch.cuda.synchronize()
