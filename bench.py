@@ -129,6 +129,33 @@ def cpu_baseline(model_cfg, with_vae=True):
                                                   if t_vae is not None else "; VAE excluded")}
 
 
+def rccl_graph_preflight(dev, world, rank):
+    """Capture one all-reduce and one all-to-all of the default process group into a hipGraph on a side stream, replay it once and
+    check the numbers: -> (ok, reason).  The collectives run once eagerly first (communicator set-up must not fall into a capture)."""
+    import torch.distributed as dist
+    try:
+        x = torch.ones(4096, device=dev)
+        a_in = torch.full((world * 256,), float(rank), device=dev)
+        a_out = torch.empty_like(a_in)
+        dist.all_reduce(x)
+        dist.all_to_all_single(a_out, a_in)
+        torch.cuda.synchronize()
+        x.fill_(1.0)
+        a_out.fill_(-1.0)
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=dev)
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+            dist.all_reduce(x)
+            dist.all_to_all_single(a_out, a_in)
+        g.replay()
+        torch.cuda.synchronize()
+        want = torch.arange(world, device=dev, dtype=torch.float32).repeat_interleave(256)
+        if abs(float(x[0]) - world) > 1e-3 or not torch.equal(a_out, want):
+            return False, f"wrong result after replay (all-reduce {float(x[0])}, expected {world})"
+        return True, None
+    except Exception as e:      # noqa: BLE001 - any failure means "do not capture collectives on this box"
+        return False, repr(e)[:300]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,10 +178,6 @@ def main():
                     help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
                          "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
                          "launch-gap cost, not the contract line")
-    ap.add_argument("--no-hipgraph", action="store_true",
-                    help="context-parallel runs (--gpus N > 1) replay every DiT forward - kernels AND RCCL collectives - from captured "
-                         "hipGraphs by default (the host side of a rank is 47 ms per block eager, 21 ms under replay, of ~120 ms of GPU "
-                         "work at 8 ranks: profiles/r05_cp_host_probe.txt); this flag keeps them eager (A/B)")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5's weight path (reference enable_fp8: e4m3 weights + dynamic per-tensor e4m3 "
                          "activations in every nn.Linear).  NOT the headline precision: the line is flagged dtype fp8 and "
@@ -185,6 +208,13 @@ def main():
                          "replicas = one independent stream per GPU (weak scaling, no collective)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints its version banner on stdout when a
+    # process group comes up or goes down): file descriptor 1 is pointed at stderr for the whole run and the line goes to the saved
+    # descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if args.cp_host_probe:
@@ -204,6 +234,7 @@ def main():
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
         sock.close()
+        os.dup2(json_fd, 1)      # the launcher and its ranks inherit the real stdout
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -255,14 +286,24 @@ def main():
         model.enable_fp8()
     use_cp = (world > 1 and args.parallel == "cp") or args.cp_host_probe
     cp_world = world if use_cp else max(1, args.simulate_cp)
-    # Context-parallel runs replay from hipGraphs by DEFAULT (r06): at N ranks the GPU work per block shrinks
-    # N-fold and the ~2650 launches + ~600 collectives a rank issues per block do not.  The kernel-class brackets cannot live inside
-    # a graph, so the timed region carries none; a DIAGNOSTIC block behind the timed region runs eagerly with every bracket on and
-    # with the exposed-communication brackets of parallel.ContextParallel (config.cp_diagnostics).  Not over gloo (shared-GPU rigs).
-    cp_graphs = world > 1 and use_cp and not args.no_hipgraph and not shared_gpu and not args.cp_host_probe
-    if cp_graphs and not args.hipgraph:
-        model.use_hip_graphs = True
-        args.profile_classes = "none"
+    # Context-parallel runs stay EAGER by default (r06).  VERDICT r05 asked for hipGraph replay as the --gpus N default; measured
+    # first: with a one-rank RCCL group made to issue its collectives for real (r05's probe short-circuited them at world 1, so its
+    # "captured with the RCCL collectives" never captured one), capturing the head-exchange forward segfaults inside
+    # hipStreamEndCapture on ROCm 7.0.2 / RCCL 2.26.6 whenever an ASYNCHRONOUS all-to-all is part of the capture (a forked branch);
+    # synchronous all-to-alls and asynchronous all-gathers capture and replay fine (profiles/r06_cp_graph_capture_bisect.txt).  A
+    # segfault cannot be caught by a pre-flight, the first run on real xGMI must not die on it, and eager costs a rank 38-47 ms of
+    # host time per block against ~117 ms of GPU work.  `--hipgraph` opts in (all-to-alls are then issued synchronously inside the
+    # capture, parallel.py) after a small RCCL-in-graph pre-flight on every rank.  Either way a DIAGNOSTIC block behind the timed
+    # region runs eagerly with every kernel class and every wait for a collective bracketed (config.cp_diagnostics).
+    cp_graph_note = None
+    if world > 1 and use_cp and args.hipgraph and not shared_gpu:
+        ok, why = rccl_graph_preflight(dev, world, rank)
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            model.use_hip_graphs = False
+            cp_graph_note = f"eager: the RCCL-in-hipGraph pre-flight failed on some rank (this rank: {why or 'ok'})"
+            print(f"[bench] rank {rank}: {cp_graph_note}", file=sys.stderr)
     if args.cp_attn_splits <= 0:   # the count that fills the 256 CUs best for this rank count (parallel.attn_kv_splits_for)
         from realtime_video_amd.parallel import attn_kv_splits_for
         args.cp_attn_splits = attn_kv_splits_for(cp_world, mc["num_heads"],
@@ -319,7 +360,10 @@ def main():
     # (the session's noise tensor is drawn in one call whose values depend on its SIZE - the generator's grid follows numel - so every
     # run reserves the diagnostic block, context parallel or not: an N-rank run and the single-GPU run of the same command see the same
     # noise and their last timed block can be compared bit for bit, tests/test_context_parallel_gpu.py)
-    n_blocks = args.warmup + args.steps + 1
+    # hipGraph replay: a forward geometry is captured on its SECOND sighting (block 2 for the recompute pass); with fewer than 3
+    # warm-up blocks the capture would fall into the timed region, so the missing ones are run as extra untimed priming blocks
+    priming = max(0, 3 - args.warmup) if model.use_hip_graphs else 0
+    n_blocks = priming + args.warmup + args.steps + 1
     params = GenerateParams(prompt="synthetic", seed=42, kv_cache_num_frames=args.kv_cache_num_frames,
                             num_blocks=n_blocks, num_denoising_steps=args.denoising_steps, keep_first_frame=keep_first)
     # frame delivery (release_server.py:978-991): every block's pixels go to pinned host memory as rgb8 on the download
@@ -348,7 +392,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(priming + args.warmup):
         sess.generate_block()
     barrier()
     ops.prof_reset()
@@ -520,6 +564,8 @@ def main():
                 f"re-encode replicated" if use_cp else f"{world} independent replicas"),
             "cp_attn_kv_splits": args.cp_attn_splits if (use_cp or args.simulate_cp > 1) else None,
             "cp_hipgraph_replay": bool(model.use_hip_graphs) if use_cp else None,
+            "cp_hipgraph_note": cp_graph_note,
+            "hipgraph_priming_blocks": priming,
             "cp_diagnostics": cp_diag,
             "dit_ms_per_denoise_step": sum(step_ms) / max(1, len(step_ms)),        # BASELINE.json "per-step DiT latency"
             "dit_ms_per_recompute_forward": sum(recompute_ms) / max(1, len(recompute_ms)) if recompute_ms else None,
@@ -584,7 +630,8 @@ def main():
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(mc, with_vae=not args.no_vae)
-    print(json.dumps(result))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(result) + "\n").encode())
 
 
 if __name__ == "__main__":

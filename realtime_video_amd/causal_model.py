@@ -649,7 +649,7 @@ class CausalWanModel:
                 self.cp_forwards_issued = getattr(self, "cp_forwards_issued", 0) + 1   # (bench.py --cp-host-probe reports it)
                 # context parallel: local rows only, ONE K/V all-gather per layer (parallel.py).  `local_ranks` is
                 # [rank] in production; a single-process simulation of several ranks runs them in lockstep.
-                from .parallel import shard_rows
+                from .parallel import shard_rows, wait_in_order
                 W, H = cp.world, self.num_heads
                 heads = cp.head_exchange(H)
                 keep = []
@@ -705,8 +705,7 @@ class CausalWanModel:
                         _lib.call("rtv_dit_layer_proj", cfg_p, w_p, ctypes.byref(st), l, PROJ_KV, W, null,
                                   c_vp(b["kv_send"].data_ptr()), *wsa)
                     pend_kv = cp.exchange_kv(bufs, kv_cache[l]["k"][0], kv_cache[l]["v"][0], row0, M, async_op=True)
-                    pend_q.wait()
-                    pend_kv.wait()
+                    wait_in_order(pend_q, pend_kv)      # one join with the communication stream (parallel.wait_in_order)
                     for (st, wsa), (_, b) in zip(parts, bufs):
                         _lib.call("rtv_dit_layer_attn_hp", cfg_p, w_p, ctypes.byref(st), l, W, c_vp(b["q_all"].data_ptr()),
                                   c_vp(b["o_all"].data_ptr()), *wsa)

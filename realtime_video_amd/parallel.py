@@ -84,6 +84,30 @@ class Pending:
             self.after()
             self.after = None
 
+    def covered(self):
+        """This exchange was issued BEFORE one on the same communication stream that has just been waited for: the stream runs its
+        collectives in order, so it is complete as well - drop the handle without a second cross-stream wait (see wait_in_order)."""
+        self.work = None
+        if self.after is not None:
+            self.after()
+            self.after = None
+
+
+def wait_in_order(*pendings):
+    """Make the compute stream wait for several exchanges issued in this order on ONE communication stream: a single wait for the
+    LAST one (in-order stream: the earlier ones are complete when it is).  One join instead of one per exchange - and the form a
+    hipGraph capture survives: two event waits into the capture stream from different points of the communication stream segfault
+    in hipStreamEndCapture on ROCm 7.0.2 / RCCL 2.26.6 (profiles/r06_cp_graph_capture_bisect.txt: q and k|v all-to-alls both in
+    flight; one join, or one exchange in flight at a time, is fine)."""
+    real = [p for p in pendings if p.work is not None]
+    if real:
+        real[-1].wait()
+    for p in pendings:
+        if p.work is not None:
+            p.covered()
+        else:
+            p.wait()          # completed / simulated exchanges: run their follow-up
+
 
 class ContextParallel(_ExchangeChoice):
     def __init__(self, group=None, exchange="auto", overlap=True, attn_kv_splits=1):
@@ -207,8 +231,13 @@ class ContextParallel(_ExchangeChoice):
             dist.all_to_all_single(host_out, inp.reshape(-1).cpu(), group=self.group)
             out.view(-1).copy_(host_out)
         else:
-            work = dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group, async_op=async_op and self.overlap)
-        return Pending(work if (async_op and self.overlap) else None, timer=(self, kind)) if async_op else out
+            # Inside a hipGraph capture the all-to-all is issued SYNCHRONOUSLY: an asynchronous one (a forked branch of the capture
+            # with the projection kernels beside it) segfaults in hipStreamEndCapture on ROCm 7.0.2 / RCCL 2.26.6, measured on a
+            # one-rank group (profiles/r06_cp_graph_capture_bisect.txt); asynchronous all-gathers capture fine.
+            go_async = async_op and self.overlap and not (inp.is_cuda and torch.cuda.is_current_stream_capturing())
+            work = dist.all_to_all_single(out.view(-1), inp.view(-1), group=self.group, async_op=go_async)
+            return Pending(work if go_async else None, timer=(self, kind)) if async_op else out
+        return Pending(None) if async_op else out
 
     def exchange_q(self, parts, async_op=False):
         """q_send -> q_all: every rank receives ALL query rows of its own heads."""
