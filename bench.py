@@ -40,7 +40,8 @@ def gemm_algorithmic_bytes(mc, M=4680):
     """Average algorithmic bytes per DiT-layer projection GEMM launch: operands read once + output written once
     (A[M,K] + W[N,K] + C[M,N] in bf16, plus the residual read where the epilogue fuses it)."""
     d, f = mc["dim"], mc["ffn_dim"]
-    shapes = [(3 * d, d, 0), (d, d, 1), (d, d, 0), (d, d, 1), (f, d, 0), (d, f, 1)]  # (N, K, fused residual)
+    # (N, K, fused residual): q|k, v, o, cross-q, cross-o, ffn-in, ffn-out - the seven projection launches of a layer since r05
+    shapes = [(2 * d, d, 0), (d, d, 0), (d, d, 1), (d, d, 0), (d, d, 1), (f, d, 0), (d, f, 1)]
     tot = sum(2 * (M * K + N * K + M * N + res * M * N) for N, K, res in shapes)
     return tot / len(shapes)
 
@@ -51,7 +52,7 @@ def measured_traffic(model):
     --pmc passes).  rocprofv3 --pmc cannot run inside this process, so the committed summary of the newest round is read;
     its sample size and file travel in the JSON line."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(root, "profiles", f"{rnd}_traffic_{model}.json")
         try:
             with open(path) as f:

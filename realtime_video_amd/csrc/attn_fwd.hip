@@ -901,7 +901,22 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, i
   const int ki = (waves == 4 ? 2 : 0) + (f16 ? 1 : 0);
   if (int st = ensure_dynamic_lds(kerns[ki], lds, &lds_attr[ki], "attn_fwd")) return st;
   const int grid = B * H * p.n_qtiles;
-  double kv_avg = Lkv;  // dense; block-causal work is smaller (reported as dense upper bound / 1)
+  // keys a query row really attends, averaged over the rows: Lkv for a dense launch; under the block-causal mask row r sees the
+  // first ((r + q_offset) / causal_block + 1) * causal_block keys (r06: the mask used to be counted as dense, which overstated
+  // the attention rate of recompute forwards over more than one block - kv_cache_num_frames 9 / 18 - in bench.py's line)
+  double kv_avg = Lkv;
+  if (causal_block > 0 && Lq > 0) {
+    double keys = 0;
+    for (int64_t r0 = 0; r0 < Lq;) {
+      const int64_t blk = (r0 + q_offset) / causal_block;
+      int64_t r1 = (blk + 1) * (int64_t)causal_block - q_offset;
+      if (r1 > Lq) r1 = Lq;
+      const int64_t lim = (blk + 1) * (int64_t)causal_block;
+      keys += (double)(r1 - r0) * (double)(lim < Lkv ? lim : Lkv);
+      r0 = r1;
+    }
+    kv_avg = keys / Lq;
+  }
   ProfScope prof(PROF_ATTN, (hipStream_t)stream, 4.0 * B * H * (double)Lq * kv_avg * ATT_D);
   const dim3 g(grid, kv_splits), t(waves * 64);
   auto combine = [&]() -> int {

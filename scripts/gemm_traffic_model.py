@@ -135,10 +135,11 @@ def main():
     print(f"M = {M} rows, bf16, default dispatch (gemm8_kernel); MB per launch; alg = operands + output once")
     print(f"{'shape':28s} {'N x K':>13s} {'rounds':>6s} {'tail':>16s} {'alg':>6s} {'floor':>6s} {'model rd':>8s} {'(A':>6s} {'W':>6s} {'slab)':>6s} "
           f"{'model wr':>8s} {'model/alg':>9s}" + (f" {'meas rd':>8s} {'meas wr':>8s} {'meas/alg':>8s} {'L2 hit':>7s} {'us':>6s}" if root else ""))
-    tot = dict(alg=0.0, model=0.0, meas=0.0, floor=0.0)
+    tot = dict(alg=0.0, model=0.0, meas=0.0, floor=0.0, n=0)
+    per_shape = []
     for i, (name, N, K, res) in enumerate(SHAPES):
         m = model(N, K, res)
-        weight = 3 if i == 1 else 1           # v, o, cross-q, cross-o: 4 launches of the shape per layer, 3 of them in the r05 6-GEMM average
+        weight = 4 if i == 1 else 1           # v, o, cross-q, cross-o: four launches of that shape per layer (seven GEMM launches in all)
         tail = "half tiles" if m["half"] else (f"split-K {m['S']} x {m['R']}" if m["S"] > 1 else ("strips" if m["strips"] else "-"))
         line = (f"{name:28s} {N:6d}x{K:<6d} {m['rounds']:6.2f} {tail:>16s} {m['alg'] / 1e6:6.0f} {m['floor'] / 1e6:6.0f} {m['reads'] / 1e6:8.0f} "
                 f"{m['a'] / 1e6:6.0f} {m['w'] / 1e6:6.0f} {m['slab'] / 1e6:6.0f} {m['writes'] / 1e6:8.0f} {(m['reads'] + m['writes']) / m['alg']:9.2f}")
@@ -149,11 +150,25 @@ def main():
                 hit = z.get("TCC_HIT_sum", 0.0) / max(z.get("TCC_HIT_sum", 0.0) + z.get("TCC_MISS_sum", 0.0), 1.0)
                 line += f" {rd / 1e6:8.0f} {wr / 1e6:8.0f} {(rd + wr) / m['alg']:8.2f} {100 * hit:6.1f}% {z.get('us', 0):6.0f}"
                 tot["meas"] += weight * (rd + wr)
+                per_shape.append({"shape": name, "N": N, "K": K, "launches_per_layer": weight, "algorithmic_bytes": m["alg"],
+                                  "model_bytes": m["reads"] + m["writes"], "read_bytes": rd, "write_bytes": wr, "l2_hit": hit,
+                                  "us_under_profiler": z.get("us", 0.0)})
+        tot["n"] += weight
         tot["alg"] += weight * m["alg"]
         tot["model"] += weight * (m["reads"] + m["writes"])
         tot["floor"] += weight * m["floor"]
         print(line)
-    print(f"layer average (shape 2 weighted x3): alg {tot['alg'] / 6e6:.0f} MB, floor {tot['floor'] / tot['alg']:.2f}x, model {tot['model'] / tot['alg']:.2f}x"
+    if root and per_shape and os.environ.get("TRAFFIC_JSON"):
+        import json
+        with open(os.environ["TRAFFIC_JSON"], "w") as f:      # the file bench.py's roofline.traffic reads (classes.gemm.*)
+            json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, own passes, 30 launches per shape and "
+                                 "pass (scripts/gemm_traffic_table.sh); read bytes = 2 x FETCH_SIZE (gfx950), write bytes = WRITE_SIZE",
+                       "classes": {"gemm": {"hbm_bytes_per_launch": tot["meas"] / tot["n"], "launches_sampled": 30 * len(per_shape) * 2,
+                                            "algorithmic_bytes_per_launch": tot["alg"] / tot["n"], "model_bytes_per_launch": tot["model"] / tot["n"],
+                                            "floor_bytes_per_launch": tot["floor"] / tot["n"], "per_shape": per_shape,
+                                            "note": "average over the seven projection launches of a layer (qk, v, o, cross-q, cross-o, ffn-in, "
+                                                    "ffn-out); the 5120 x 5120 shape was measured with the fused residual and weighted x4"}}}, f, indent=1)
+    print(f"layer average (seven launches: shape 2 weighted x4): alg {tot['alg'] / tot['n'] / 1e6:.0f} MB, floor {tot['floor'] / tot['alg']:.2f}x, model {tot['model'] / tot['alg']:.2f}x"
           + (f", measured {tot['meas'] / tot['alg']:.2f}x" if tot["meas"] else ""))
 
 

@@ -19,4 +19,4 @@ for shape in "10240 5120 0" "5120 5120 1" "13824 5120 0" "5120 13824 1"; do
   done
 done
 cd $R
-python scripts/gemm_traffic_model.py $RAW | tee $OUT/table${TAG:+_$TAG}.txt
+TRAFFIC_JSON=$OUT/traffic${TAG:+_$TAG}.json python scripts/gemm_traffic_model.py $RAW | tee $OUT/table${TAG:+_$TAG}.txt
