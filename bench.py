@@ -273,6 +273,10 @@ def main():
     if os.environ.get("RTV_ROPE_WAVE") is not None:      # A/B of the RoPE / cache kernel forms (include/rtv_hip_lab.h), diagnostic
         from realtime_video_amd import _lib
         _lib.load().rtv_rope_set_wave(int(os.environ["RTV_ROPE_WAVE"]))
+    if os.environ.get("RTV_FRESH_TAP_SKIP") is not None:   # A/B of the fresh one-frame encode (last time tap only vs all 27 taps), diagnostic
+        from realtime_video_amd import _lib
+        import realtime_video_amd.vae_encoder  # noqa: F401  (registers the signature)
+        _lib.call("rtv_vae_set_fresh_tap_skip", int(os.environ["RTV_FRESH_TAP_SKIP"]))
     if os.environ.get("RTV_DIRECT_V") is not None:       # A/B of the V cache write (GEMM epilogue vs copy, include/rtv_hip_lab.h), diagnostic
         from realtime_video_amd import _lib
         _lib.load().rtv_dit_set_direct_v(int(os.environ["RTV_DIRECT_V"]))

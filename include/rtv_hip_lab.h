@@ -54,6 +54,11 @@ int rtv_dit_set_direct_v(int on);
  * Bit-identical: both forms sum a row's squares in ONE canonical order (four accumulators per lane column, combined, then the
  * 64-lane butterfly; tests/test_kernels_gpu.py::test_qk_norm_rope_cache_forms_are_bit_identical). */
 int rtv_rope_set_wave(int mode);
+/* VAE encoder, first chunk of a stream (one frame on fresh caches; the T2V path re-encodes one frame per block, release_server.py:572-575):
+ * 1 (default) = every causal 3x3x3 convolution runs its LAST time tap only, as a 1x3x3 convolution of the new frame - the two cached
+ * slices are the zero padding of vae.py:17-36, taps 0-17 multiply zeros; 0 = the full 27-tap launch over the zero slices.
+ * Bit-identical (the surviving products accumulate in the same order), a third of the matrix work. */
+int rtv_vae_set_fresh_tap_skip(int on);
 /* 1 when the library was built with -DRTV_LAB (experimental kernels present), else 0. */
 int rtv_lab_build(void);
 

@@ -68,4 +68,10 @@ int qk_norm_rope_launch(const void* qkv, void* q_out, void* k_cache, void* v_cac
                         int parts /* 1 = q, 2 = k and v, 3 = all */, rtv_stream_t stream);
 int regroup_heads(const void* in, void* out, int rows, int G, int group_cols, rtv_stream_t stream);
 
+// vae_conv.hip: the last time tap of a 3x3x3 causal convolution as a 1x3x3 convolution of one new frame (fresh streams: the two
+// cached slices are zeros), weight used in place; gamma != null: with the fused RMS_norm + SiLU epilogue (returns 1 where the layer
+// has none).  Bit-identical with the full launch.
+int conv3_last_tap(const void* frame, const void* w3, const void* bias, const void* gamma, const void* residual, int res_ld, void* out,
+                   int out_ld, int H, int W, int Cin, int Cout, int flags, const void* zeros, hipStream_t stream);
+
 }  // namespace rtv

@@ -34,6 +34,9 @@ struct ConvParams {
   int inH, inW;     // input grid (H >> ups)
   int Cin, Cout;
   int kt, kh, kw;
+  int w_taps;       // taps per filter row of `w` (its row stride is w_taps * Cin elements): kt * kh * kw, or MORE when the launch uses
+                    // a suffix of a wider tap set in place - the last time tap of a 3x3x3 weight as a 1x3x3 convolution (w points at
+                    // tap 18 of filter 0, w_taps = 27: the fresh one-frame VAE encode, whose two cached time slices are zeros)
   int ups;          // 1: input is read through a nearest 2x upsampling
   int sy, st;       // spatial / temporal stride of the output grid over the input (1 or 2)
   int pad_h, pad_w; // low-side zero padding (kh/2 for 'same' convs, 0 for the stride-2 downsample: its ZeroPad2d is high-side)
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_kernel(ConvParams p) {
     base_off[i] = ((pt * p.st * p.inH + ((yb >> p.ups) - p.y_in0)) * p.inW + (xb >> p.ups)) * p.Cin + Cfg::swz(row, cpos) * 8;
   }
   uint32_t b_off[Cfg::B_INST];
-  const int Ktot = p.kt * p.kh * p.kw * p.Cin;
+  const int Ktot = p.w_taps * p.Cin;   // weight row stride (elements)
 #pragma unroll
   for (int i = 0; i < Cfg::B_INST; ++i) {
     int row = (wave * Cfg::B_INST + i) * Cfg::RPI + rsub;
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(ch::THREADS, 2) void conv_halo_kernel(ConvParams p,
   const int cpk = p.Cin / 32;                      // channel chunks per time slice
   const int G = p.kt * cpk;                        // (dt, chunk) groups (kt = 3: causal 3x3x3; kt = 1: the 3x3 conv behind the
   const int slice = p.inH * p.inW * p.Cin;         //  nearest-2x upsampling, r05)
-  const int taps = 9 * p.kt;
+  const int taps = p.w_taps;   // weight row stride in taps (9 * kt unless the launch uses a tap suffix in place)
 
   // ---- halo DMA geometry: wave w issues pieces 5w .. 5w+4 (piece 39 repeats 38); lane -> halo pixel q = 16 piece + lane / 4,
   //      LDS slot lane % 4, source chunk = slot ^ key(halo column)
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(ch4::THREADS4, 1) void conv_halo4_kernel(ConvParams
   const int cpk = p.Cin / 32;
   const int G = p.kt * cpk;
   const int slice = p.inH * p.inW * p.Cin;
-  const int taps = 9 * p.kt;
+  const int taps = p.w_taps;   // weight row stride in taps (9 * kt unless the launch uses a tap suffix in place)
 
   // ---- halo DMA geometry (conv_halo_kernel's pieces, ten per wave): piece -> 16 halo pixels x 64 bytes.  Buffer addressing: the
   //      per-lane BYTE offset of the pixel's chunk at (dt 0, channel chunk 0) in a VGPR, the group's offset in an SGPR - no vector
@@ -983,7 +986,7 @@ __global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_pe
   const int cpk = p.Cin / 32;
   const int G = p.kt * cpk;
   const int slice = p.inH * p.inW * p.Cin;
-  const int taps = 9 * p.kt;
+  const int taps = p.w_taps;   // weight row stride in taps (9 * kt unless the launch uses a tap suffix in place)
 
   auto decode = [&](int vid, int& t, int& y0, int& x0, int& n0) __attribute__((always_inline)) {
     const int id = xcd_remap(vid, total);
@@ -1361,7 +1364,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   const bool halo3 = halo_common && p.kt == 3 && !p.ups && p.y_out0 == 0 && p.y_in0 == 0 && p.in_rows == p.inH && p.limH == p.inH &&
                      p.limW == p.inW;
   const bool halo_up = halo_common && p.kt == 1 && p.ups && p.limW == p.W;
-  const bool halo = halo3 || halo_up;
+  // r06: the LAST time tap of a 3x3x3 layer run as a 1x3x3 convolution over the newest slice (w_taps = 27: the weight is used in
+  // place): the same layer on the same kernel, one (time slice) group per channel chunk instead of three
+  const bool halo1 = halo_common && p.kt == 1 && !p.ups && p.w_taps == 27 && p.y_out0 == 0 && p.y_in0 == 0 && p.in_rows == p.inH &&
+                     p.limH == p.inH && p.limW == p.inW;
+  const bool halo = halo3 || halo_up || halo1;
   if (p.norm_gamma && !(halo && p.Cout == 96 && !p.residual && !((uintptr_t)p.norm_gamma & 7)))
     return set_error(-1, "conv: the fused RMS_norm + SiLU epilogue needs a halo-kernel layer with 96 filters and no residual");
   if (halo) {
@@ -1449,11 +1456,59 @@ extern "C" int rtv_conv3_norm_silu_cl(const void* in, const void* w, const void*
   p.Cin = Cin;
   p.Cout = Cout;
   p.kt = p.kh = p.kw = 3;
+  p.w_taps = 27;
   p.ups = 0;
   p.n_split = 0;
   p.M = T * H * W;
   p.tiles_m = p.tiles_n = 0;
   return launch_conv(p, (hipStream_t)stream);
+}
+
+/* The 3x3x3 causal convolution of ONE new frame over two all-zero cached slices (a fresh stream: vae.py:17-36 pads zeros in front of
+ * the first chunk) = the 1x3x3 convolution of that frame with the LAST time tap of the weight: taps 0-17 multiply zeros.  `frame` =
+ * the new slice [H][W][Cin] (slice 2 of the concat buffer), `w3` = the 3x3x3 weight [Cout][27][Cin] used in place.  Same kernel per
+ * layer as rtv_conv_cl / rtv_conv3_norm_silu_cl (gamma != null: the fused RMS_norm + SiLU epilogue, 96 filters on the halo kernel),
+ * the surviving products in the same order: bit-identical with the full launch, a third of its matrix work.  Returns 1 (nothing
+ * launched) where a fused epilogue is asked for on a layer that has none. */
+int rtv::conv3_last_tap(const void* frame, const void* w3, const void* bias, const void* gamma, const void* residual, int res_ld,
+                        void* out, int out_ld, int H, int W, int Cin, int Cout, int flags, const void* zeros, hipStream_t stream) {
+  if (!frame || !w3 || !out || !zeros) return set_error(-1, "conv: null pointer");
+  const int gather = (flags & RTV_CONV_GATHER) ? 1 : 0;
+  if (gamma && (!g_conv_fuse_norm || !g_conv_halo || gather || Cout != 96 || Cin % 32 || Cin > 384 || (out_ld & 7) || residual ||
+                ((uintptr_t)out & 15) || ((uintptr_t)gamma & 7)))
+    return 1;
+  ConvParams p;
+  p.in = (const uint16_t*)frame;
+  p.w = (const uint16_t*)w3 + (size_t)18 * Cin;
+  p.out = (uint16_t*)out;
+  p.bias = (const uint16_t*)bias;
+  p.residual = (const uint16_t*)residual;
+  p.zeros = (const uint16_t*)zeros;
+  p.out_ld = out_ld;
+  p.res_ld = res_ld;
+  p.T = 1;
+  p.H = H;
+  p.W = W;
+  p.inH = H;
+  p.inW = W;
+  p.sy = p.st = 1;
+  p.pad_h = p.pad_w = 1;
+  p.limH = H;
+  p.limW = W;
+  p.y_out0 = p.y_in0 = 0;
+  p.in_rows = H;
+  p.gather = gather;
+  p.norm_gamma = (const uint16_t*)gamma;
+  p.Cin = Cin;
+  p.Cout = Cout;
+  p.kt = 1;
+  p.kh = p.kw = 3;
+  p.w_taps = 27;
+  p.ups = 0;
+  p.n_split = 0;
+  p.M = H * W;
+  p.tiles_m = p.tiles_n = 0;
+  return launch_conv(p, stream);
 }
 
 extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, const void* residual, int res_ld,
@@ -1516,6 +1571,7 @@ extern "C" int rtv_conv_cl_win(const void* in, const void* w, const void* bias, 
   p.kt = kt;
   p.kh = kh;
   p.kw = kw;
+  p.w_taps = kt * kh * kw;
   p.ups = ups ? 1 : 0;
   p.n_split = n_split;
   p.M = T * H * W;

@@ -371,12 +371,17 @@ extern "C" int rtv_vae_cache_slot(int h, int w, int slot, size_t* offset, int* C
 
 namespace {
 
+static std::atomic<bool> g_fresh_tap_skip{true};   // rtv_vae_set_fresh_tap_skip (include/rtv_hip_lab.h)
+
 struct Ctx {
   char* arena;
   const VaeLayout* L;
   int h, wd;
   hipStream_t stream;
   int act_next;
+  // encoder, first chunk of a stream (ONE frame over zero caches): the causal 3x3x3 convolutions run their last time tap only
+  // (conv3_last_tap: taps 0-17 would multiply the zero slices; bit-identical, a third of the matrix work)
+  bool fresh = false;
   uint16_t* act(int i) { return (uint16_t*)(arena + L->act_off[i & 3]); }
   uint16_t* cat(int i) { return (uint16_t*)(arena + L->cat_off[i]); }
   const void* zeros() { return arena + L->zeros_off; }
@@ -389,8 +394,13 @@ static int cached_conv3(Ctx& c, int ci, int T, int H, int W, int Cin, const rtv_
   uint16_t* buf = c.cat(ci);
   // latent-resolution layers (mid block, first stage: W == the latent width in sharded and unsharded decodes alike) stay on
   // the gather kernel - 16 halo tiles per frame cannot fill the chip (scripts/conv_bench.py: 315 vs 399 TF/s at 60 x 104)
-  RTV_TRY(rtv_conv_cl(buf, cw.w, cw.b, residual, Cout, out, out_ld, T, H, W, Cin, Cout, 3, 3, 3,
-                      W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE, 0, c.zeros(), c.stream));
+  const int flags = W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE;
+  if (c.fresh && T == 1) {
+    RTV_TRY(conv3_last_tap(buf + 2 * (size_t)H * W * Cin, cw.w, cw.b, nullptr, residual, Cout, out, out_ld, H, W, Cin, Cout, flags,
+                           c.zeros(), c.stream));
+  } else {
+    RTV_TRY(rtv_conv_cl(buf, cw.w, cw.b, residual, Cout, out, out_ld, T, H, W, Cin, Cout, 3, 3, 3, flags, 0, c.zeros(), c.stream));
+  }
   return roll_cache(c, ci, T, H, W, Cin);
 }
 
@@ -419,9 +429,13 @@ static int res_block(Ctx& c, int ci, int T, int H, int W, int cin, int cout, con
   // conv_a -> RMS_norm -> SiLU: one launch where the conv kernel holds all channels of a pixel (96 filters, halo kernel), with
   // the normalised activation written straight into conv_b's concat buffer; else conv into `tmp` + the separate pass
   {
-    int st = cout == 96 ? rtv_conv3_norm_silu_cl(c.cat(ci), rw.conv_a.w, rw.conv_a.b, rw.gamma3, c.cat(ci + 1) + 2 * sl_out, cout, T, H,
-                                                  W, cin, cout, W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE, c.zeros(), c.stream)
-                        : 1;
+    const int flags = W == c.wd ? RTV_CONV_GATHER : RTV_CONV_NONE;
+    int st = cout != 96 ? 1
+             : (c.fresh && T == 1)
+                 ? conv3_last_tap(c.cat(ci) + 2 * sl_in, rw.conv_a.w, rw.conv_a.b, rw.gamma3, nullptr, 0, c.cat(ci + 1) + 2 * sl_out, cout,
+                                  H, W, cin, cout, flags, c.zeros(), c.stream)
+                 : rtv_conv3_norm_silu_cl(c.cat(ci), rw.conv_a.w, rw.conv_a.b, rw.gamma3, c.cat(ci + 1) + 2 * sl_out, cout, T, H, W, cin,
+                                          cout, flags, c.zeros(), c.stream);
     if (st < 0) return st;
     if (st == 0) {
       RTV_TRY(roll_cache(c, ci, T, H, W, cin));
@@ -770,6 +784,7 @@ extern "C" int rtv_vae_encode(const rtv_vae_enc_weights* w, const void* frames, 
   hipStream_t stream = (hipStream_t)stream_;
   const int h = H >> 3, wd = W >> 3;
   Ctx c{(char*)arena, &L, h, wd, stream, 0};
+  c.fresh = first && g_fresh_tap_skip.load(std::memory_order_relaxed);
   if (L.ldp != h * wd)
     if (hipMemsetAsync((char*)arena + L.vt_off, 0, (size_t)384 * L.ldp * 2, stream) != hipSuccess)
       return set_error(-1, "vae_encode: memset failed");
@@ -859,5 +874,10 @@ extern "C" int rtv_vae_encode(const rtv_vae_enc_weights* w, const void* frames, 
                        (const float*)w->std, (f16_t*)mu, Tout_tot, tout);
     RTV_TRY(check_launch("vae_enc_final"));
   }
+  return 0;
+}
+
+extern "C" int rtv_vae_set_fresh_tap_skip(int on) {   // include/rtv_hip_lab.h
+  g_fresh_tap_skip.store(on != 0, std::memory_order_relaxed);
   return 0;
 }

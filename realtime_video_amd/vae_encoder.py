@@ -28,6 +28,7 @@ class _VaeEncWeights(ctypes.Structure):
 
 
 _lib.EXTRA_SIGNATURES.update({
+    "rtv_vae_set_fresh_tap_skip": [c_int],      # include/rtv_hip_lab.h (A/B switch for the tests)
     "rtv_vae_encode": [ctypes.POINTER(_VaeEncWeights), c_vp] + [c_int] * 6 + [c_vp, ctypes.c_size_t, c_vp, c_int, c_int, c_vp],
     "rtv_vae_enc_cache_slot": [c_int, c_int, c_int, ctypes.POINTER(ctypes.c_size_t)] + [ctypes.POINTER(c_int)] * 4,
 })

@@ -474,6 +474,37 @@ def test_streaming_encoder_matches_reference_golden(golden):
     assert mu1.shape == (1, 16, 1, 8, 12) and max_abs(mu1.float().cpu(), g["mu"][0][:, :, :1]) <= 3e-2
 
 
+@pytest.mark.parametrize("size", [(64, 96), (480, 832)])
+def test_fresh_one_frame_encode_runs_the_last_time_tap_only_and_is_bit_identical(size):
+    """r06: the first chunk of an encoder stream is ONE frame over zero caches (vae.py:17-36 pads two zero slices in front;
+    release_server.py:572-575 runs exactly this once per block), so taps 0-17 of every causal 3x3x3 convolution multiply zeros.
+    The native encoder runs the last time tap only (`conv3_last_tap`: the weight used in place through its row stride, the new
+    slice as a 1x3x3 convolution, the same kernel per layer) - a third of the matrix work - and must give the SAME BITS as the
+    full 27-tap launch over the zero slices (`rtv_vae_set_fresh_tap_skip(0)`): latents, every cache slot, and the streamed
+    chunk that follows on those caches."""
+    from realtime_video_amd import _lib
+    from realtime_video_amd.vae_encoder import VAEEncoderWrapper
+    H, W = size
+    g = torch.Generator().manual_seed(29)
+    frames = (torch.rand(1, 3, 5, H, W, generator=g) * 2 - 1).half().to(DEV)
+    outs = []
+    try:
+        for skip in (1, 0):
+            _lib.call("rtv_vae_set_fresh_tap_skip", skip)
+            enc = VAEEncoderWrapper(device=DEV).init_random_weights(seed=4)
+            mu0, cache = enc(frames[:, :, :1], [None] * 55, stream=False)
+            snap = [None if c is None else c.clone() for c in cache]
+            mu1, cache = enc(frames[:, :, 1:5], cache, stream=True)
+            outs.append((mu0.clone(), snap, mu1.clone(), [None if c is None else c.clone() for c in cache]))
+    finally:
+        _lib.call("rtv_vae_set_fresh_tap_skip", 1)
+    (a0, ca, a1, cb), (b0, cc, b1, cd) = outs
+    assert torch.isfinite(a0.float()).all() and float(a0.float().abs().max()) > 0
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    for x, y in list(zip(ca, cc)) + list(zip(cb, cd)):
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
+
+
 def test_encoder_rejects_cpu_and_bad_chunks():
     from realtime_video_amd.vae_encoder import VAEEncoderWrapper
     enc = VAEEncoderWrapper(device=DEV).init_random_weights()
