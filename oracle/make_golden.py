@@ -615,8 +615,19 @@ def golden_loader_manifest(ref):
         out[name]["fused"] = {k: list(v.shape) for k, v in wrapper.state_dict().items()}
         print(name, len(out[name]["unfused"]), "keys unfused,", len(out[name]["fused"]), "fused,",
               sum(int(torch.Size(v).numel()) for v in out[name]["unfused"].values()) / 1e9, "G parameters")
+        # stored compactly: the 40 / 30 blocks carry the same names and shapes (asserted here), so one block's entries under the
+        # placeholder index "{i}" + the layer count reproduce the full table (tests/test_checkpoint_loader.py: manifest())
+        for form in ("unfused", "fused"):
+            full = out[name][form]
+            pre = "model.blocks."
+            per = {k[len(pre):].split(".", 1)[1]: v for k, v in full.items() if k.startswith(pre + "0.")}
+            for i in range(a["num_layers"]):
+                assert {k[len(pre):].split(".", 1)[1]: v for k, v in full.items() if k.startswith(f"{pre}{i}.")} == per, (name, form, i)
+            top = {k: v for k, v in full.items() if not k.startswith(pre)}
+            assert len(top) + a["num_layers"] * len(per) == len(full)
+            out[name][form] = {"top": top, "per_block": {pre + "{i}." + k: v for k, v in per.items()}, "num_keys": len(full)}
     with open(os.path.join(OUT, "checkpoint_manifest.json"), "w") as f:
-        json.dump(out, f, indent=0, sort_keys=True)
+        json.dump(out, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -23,8 +23,20 @@ ARCHS = ["Wan2.1-T2V-14B", "Wan2.1-T2V-1.3B"]
 
 
 def manifest():
+    """{model name: {"arch": dims, "unfused" / "fused": {state-dict key: shape}}} - the fixture stores one block's entries under the
+    placeholder index "{i}" (the generator asserted that all blocks carry the same names and shapes) and is expanded here."""
     with open(os.path.join(GOLDEN, "checkpoint_manifest.json")) as f:
-        return json.load(f)
+        raw = json.load(f)
+    out = {}
+    for name, ent in raw.items():
+        out[name] = {"arch": ent["arch"]}
+        for form in ("unfused", "fused"):
+            full = dict(ent[form]["top"])
+            for i in range(ent["arch"]["num_layers"]):
+                full.update({k.replace("{i}", str(i)): v for k, v in ent[form]["per_block"].items()})
+            assert len(full) == ent[form]["num_keys"]
+            out[name][form] = full
+    return out
 
 
 def server_load_sequence(state_dict, model_name, device):
