@@ -633,7 +633,7 @@ def main():
                 for name, v in prof.items() if name in ("attn", "conv", "layernorm", "rope") and v["ms"] > 0},
         },
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the CPU baseline belongs to the N = 1 line only (rank 0's host cores, ~2 min)
         result["cpu_baseline"] = cpu_baseline(mc, with_vae=not args.no_vae)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(result) + "\n").encode())
