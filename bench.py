@@ -171,10 +171,14 @@ def main():
                     help="kernel classes bracketed with hipEvents inside the timed region: 'gemm,attn,conv,layernorm,rope' (the roofline "
                          "kernel, the attention kernels, the VAE convolutions and the HBM-bound row kernels, default), 'all' "
                          "(diagnostic: every launch) or 'none'")
-    ap.add_argument("--profile-stride", default="gemm=13,attn=5,layernorm=11,rope=7,conv=3",
+    ap.add_argument("--profile-stride", default="gemm=29,attn=11,layernorm=23,rope=17,conv=3",
                     help="bracket only every n-th launch of a class (an event pair costs the launch stream ~2.5 us per record: "
                          "bracketing all ~2.4 k GEMM launches of a block cost it ~12 ms, the ~940 row-kernel launches 9 ms - "
-                         "profiles/r04_bench_bracket_overhead.txt); class times are the sampled times scaled by work")
+                         "profiles/r04_bench_bracket_overhead.txt); class times are the sampled times scaled by work.  r06: the r04-r05 "
+                         "strides (13 / 5 / 11 / 7 / 3) still cost a block 2.4 ms; these cost 0.5 ms and read the same rates "
+                         "(roofline.frac 0.5176 vs 0.5177, attention 1103-1106 vs 1101-1103 TF/s: profiles/r06_bracket_stride_ab.txt). "
+                         "Strides are coprime with the launches per layer of their class (7 GEMMs, 2 attention, 3 LayerNorm), so the "
+                         "sample cycles through every shape; the convolutions keep 3: few launches of very different sizes")
     ap.add_argument("--hipgraph", action="store_true",
                     help="replay every DiT forward from a captured hipGraph (SURVEY 8f-2).  Kernel launches inside a graph "
                          "cannot be bracketed with events, so this run carries no roofline block: a diagnostic of the "
