@@ -617,6 +617,9 @@ def main():
             "whole_block_frac": (block_tflop / (elapsed / args.steps) / (MFMA_PEAK_TFLOPS * (2.0 if args.fp8 else 1.0))
                                  if block_tflop is not None else None),
             "whole_block_TFLOP": block_tflop,
+            "whole_block_note": ("SURVEY 8d's algorithmic count, incl. 2.72 TF for the first-frame re-encode as the reference runs it; since "
+                                 "r06 the native encoder skips the 1.8 TF of it that multiply the two zero cache slices of a fresh "
+                                 "stream (0.23 % of the block's count)") if block_tflop is not None else None,
             "launches": gm["launches"],                  # bracketed with events (every `sample_stride`-th launch of the class)
             "launches_in_timed_region": gm["seen_launches"],
             "sample_stride": 1 if args.profile_classes == "all" else strides.get("gemm", 1),
