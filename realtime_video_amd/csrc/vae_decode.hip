@@ -274,6 +274,11 @@ struct VaeLayout {
   // persistent: 32 concat buffers (2 cache slices + Tmax new slices each)
   size_t cat_off[32];
   int cat_C[32], cat_stage[32], cat_T[32];
+  // r06: a concat buffer may hold MORE than 2 + Tmax slices (cat_cap): a call then slides its [cache | new] window forward by the
+  // frame's T slices per latent frame instead of copying the last two slices to the front after every frame (roll_cache), and
+  // copies once when the window reaches the end / at the end of the call.  cat_slice = bytes per [H][W][C] slice.
+  int cat_cap[32];
+  size_t cat_slice[32];
   size_t act_off[4];   // rotating activation buffers (max activation size)
   size_t s_off, p_off, q_off, k_off, vt_off, o_off, xn_off;  // mid-block attention scratch
   size_t head_off;     // [T][H][W][8]
@@ -281,6 +286,8 @@ struct VaeLayout {
   size_t total;
   int ldp;
 };
+
+constexpr int SLIDE_FRAMES = 3;   // latent frames a decoder concat buffer takes before its cache slices are copied to the front
 
 // concat-buffer table in execution order: (channels, stage, Tmax)
 static void build_layout(int h, int w, const RowPlan& plan, VaeLayout* L) {
@@ -303,7 +310,12 @@ static void build_layout(int h, int w, const RowPlan& plan, VaeLayout* L) {
     L->cat_C[i] = C[i];
     L->cat_stage[i] = s;
     L->cat_T[i] = Tm[s];
-    L->cat_off[i] = take((size_t)(2 + Tm[s]) * hw * C[i] * 2);
+    // three latent frames (one block of the session loop) per copy; the two time_conv buffers (their cache rules are not a plain
+    // "last two slices": vae_block3.py:56-62) keep the one-frame form
+    const bool time_conv_buf = i == 11 || i == 18;
+    L->cat_cap[i] = 2 + (time_conv_buf ? 1 : SLIDE_FRAMES) * Tm[s];
+    L->cat_slice[i] = hw * C[i] * 2;
+    L->cat_off[i] = take((size_t)L->cat_cap[i] * L->cat_slice[i]);
   }
   // largest activation: max over stages of T*H*W*C
   size_t amax = 0;
@@ -382,8 +394,9 @@ struct Ctx {
   // encoder, first chunk of a stream (ONE frame over zero caches): the causal 3x3x3 convolutions run their last time tap only
   // (conv3_last_tap: taps 0-17 would multiply the zero slices; bit-identical, a third of the matrix work)
   bool fresh = false;
+  int pos[32] = {};   // first slice of concat buffer i's current [2 cached | T new] window (slides inside a call, 0 between calls)
   uint16_t* act(int i) { return (uint16_t*)(arena + L->act_off[i & 3]); }
-  uint16_t* cat(int i) { return (uint16_t*)(arena + L->cat_off[i]); }
+  uint16_t* cat(int i) { return (uint16_t*)(arena + L->cat_off[i] + (size_t)pos[i] * L->cat_slice[i]); }
   const void* zeros() { return arena + L->zeros_off; }
 };
 
@@ -404,19 +417,37 @@ static int cached_conv3(Ctx& c, int ci, int T, int H, int W, int Cin, const rtv_
   return roll_cache(c, ci, T, H, W, Cin);
 }
 
-// the causal conv's feature cache: the last two input slices move to the front of the concat buffer (vae.py:17-36)
-static int roll_cache(Ctx& c, int ci, int T, int H, int W, int Cin) {
-  uint16_t* buf = c.cat(ci);
-  const size_t slice = (size_t)H * W * Cin * 2;
-  char* b = (char*)buf;
-  if (T == 1) {
+// the causal conv's feature cache = the last two input slices (vae.py:17-36).  Where the concat buffer has room for another frame
+// behind the current window, the window just SLIDES forward by T slices - the cache is where it is, nothing moves (r06: the copies
+// of this function were the ~150 D2D copyBuffer launches of a block, 2.6 ms); otherwise the two slices are copied to the front.
+static int cache_to_front(Ctx& c, int ci, int from) {
+  char* b = c.arena + c.L->cat_off[ci];
+  const size_t slice = c.L->cat_slice[ci];
+  c.pos[ci] = 0;
+  if (from == 0) return 0;
+  if (from == 1) {   // overlapping: slice 1 -> 0, then 2 -> 1
     if (hipMemcpyAsync(b, b + slice, slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess ||
         hipMemcpyAsync(b + slice, b + 2 * slice, slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
       return set_error(-1, "vae: cache roll memcpy failed");
-  } else {
-    if (hipMemcpyAsync(b, b + (size_t)T * slice, 2 * slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
-      return set_error(-1, "vae: cache roll memcpy failed");
+    return 0;
   }
+  if (hipMemcpyAsync(b, b + (size_t)from * slice, 2 * slice, hipMemcpyDeviceToDevice, c.stream) != hipSuccess)
+    return set_error(-1, "vae: cache roll memcpy failed");
+  return 0;
+}
+static int roll_cache(Ctx& c, int ci, int T, int H, int W, int Cin) {
+  if ((size_t)H * W * Cin * 2 != c.L->cat_slice[ci]) return set_error(-1, "vae: concat buffer geometry mismatch");
+  const int np = c.pos[ci] + T;                                  // the cache is slices [np, np + 2) now
+  if (np + 2 + c.L->cat_T[ci] <= c.L->cat_cap[ci]) {             // room for the largest next frame: slide
+    c.pos[ci] = np;
+    return 0;
+  }
+  return cache_to_front(c, ci, np);
+}
+// end of a call: every window back to the front (the cache slots the caller sees are the first two slices of each buffer)
+static int flush_caches(Ctx& c, int n) {
+  for (int i = 0; i < n; ++i)
+    if (c.pos[i]) RTV_TRY(cache_to_front(c, i, c.pos[i]));
   return 0;
 }
 
@@ -614,7 +645,7 @@ static int vae_decode_impl(const rtv_vae_weights* w, const void* z, int T, int h
       out_frame += Tn;
     }
   }
-  return 0;
+  return flush_caches(c, 32);
 }
 
 extern "C" int rtv_vae_decode_rows(const rtv_vae_weights* w, const void* z, int T, int h, int wd, int first, int row0,
@@ -716,6 +747,8 @@ static void build_enc_layout(int H, int W, VaeLayout* L) {
     L->cat_C[i] = C[i];
     L->cat_stage[i] = S[i];
     L->cat_T[i] = Tm[i];
+    L->cat_cap[i] = 2 + Tm[i];          // the encoder rolls after every chunk (one chunk per call)
+    L->cat_slice[i] = hw * C[i] * 2;
     L->cat_off[i] = take((size_t)(2 + Tm[i]) * hw * C[i] * 2);
   }
   // widest activation: 4 x H x W x 96 (stage 0); 4 x H/2 x W/2 x 192 is half of it
@@ -874,7 +907,7 @@ extern "C" int rtv_vae_encode(const rtv_vae_enc_weights* w, const void* frames, 
                        (const float*)w->std, (f16_t*)mu, Tout_tot, tout);
     RTV_TRY(check_launch("vae_enc_final"));
   }
-  return 0;
+  return flush_caches(c, 24);   // (a no-op today: the encoder's buffers hold one chunk, every roll copies)
 }
 
 extern "C" int rtv_vae_set_fresh_tap_skip(int on) {   // include/rtv_hip_lab.h
